@@ -1,0 +1,17 @@
+"""MI355X-native distributed ResNet training framework.
+
+Python package layout:
+
+* `models/`     layer-graph IR and the model zoo (ResNet-50 v1.5, ResNet-20/32/56/110, trivial)
+* `engine/`     flat variable store, PyTorch reference executor, native HIP executor
+* `ops/`        hand-written HIP kernels for gfx950 (`csrc/`), their Python bindings and
+                the PyTorch reference implementations used as numerical oracles
+* `parallel/`   cluster spec, communicator (RCCL / gloo), bucketed all-reduce, strategies,
+                asynchronous parameter server
+* `train/`      Keras-like Model, callbacks, optimizers, schedules, stats, shared driver
+* `data/`       synthetic, CIFAR-10 binary, ImageNet TFRecord input pipelines
+* `checkpoint/` pure-Python HDF5 writer/reader with the Keras model layout
+* `utils/`      flags, logging, benchmark logger, TFRecord/proto codec
+* `hvd`         Horovod-style facade;  `launch`  one-process-per-GPU launcher
+"""
+__version__ = "0.1.0"

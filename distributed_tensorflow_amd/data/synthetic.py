@@ -1,0 +1,63 @@
+"""Synthetic input: one random batch resident on the device, returned every step.
+
+Parity with the reference's `common.get_synth_input_fn` (`common.py:311-359`) and
+`distribution_utils.set_up_synthetic_data` (call site `resnet_imagenet_main.py:131`):
+a single truncated-normal(127, 60) image `[H, W, C]` repeated over the batch, and
+one label drawn uniformly from `[0, num_classes - 1)` (so the last class is never
+hit, `common.py:344-347`) cast to float32 with shape `[N, 1]`.  No host->device
+copy and no input pipeline run inside the training loop.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+__all__ = ["SyntheticDataset", "get_synth_input_fn"]
+
+
+class SyntheticDataset:
+  """Infinite dataset that yields the same device-resident `(images, labels)` pair."""
+
+  def __init__(self, height, width, channels, num_classes, batch_size,
+               device: Optional[torch.device] = None, dtype=torch.float32, seed: int = 0,
+               per_sample_random: bool = False):
+    gen = torch.Generator().manual_seed(seed)
+    if per_sample_random:
+      img = torch.empty(batch_size, height, width, channels)
+    else:
+      img = torch.empty(height, width, channels)
+    torch.nn.init.trunc_normal_(img, mean=127.0, std=60.0, a=127.0 - 120.0, b=127.0 + 120.0,
+                                generator=gen)
+    if per_sample_random:
+      lab = torch.randint(0, max(num_classes - 1, 1), (batch_size, 1), generator=gen)
+      images = img
+      labels = lab.to(torch.float32)
+    else:
+      lab = torch.randint(0, max(num_classes - 1, 1), (1,), generator=gen)
+      images = img.unsqueeze(0).expand(batch_size, -1, -1, -1).contiguous()
+      labels = lab.to(torch.float32).unsqueeze(0).expand(batch_size, 1).contiguous()
+    device = torch.device(device) if device is not None else torch.device("cpu")
+    self.images = images.to(device=device, dtype=dtype)
+    self.labels = labels.to(device)
+    self.batch_size = batch_size
+
+  def __iter__(self):
+    while True:
+      yield self.images, self.labels
+
+
+def get_synth_input_fn(height, width, num_channels, num_classes, dtype=torch.float32,
+                       drop_remainder=True, device=None, per_sample_random=False):
+  """Returns `input_fn(is_training, data_dir, batch_size, *args, **kwargs)`."""
+  del drop_remainder
+
+  def input_fn(is_training, data_dir, batch_size, *args, **kwargs):
+    del data_dir, args
+    dev = kwargs.get("device", device)
+    return SyntheticDataset(height, width, num_channels, num_classes, batch_size, dev,
+                            dtype if isinstance(dtype, torch.dtype) else torch.float32,
+                            seed=0 if is_training else 1,
+                            per_sample_random=per_sample_random)
+
+  return input_fn

@@ -1,0 +1,338 @@
+"""Keras-like `Model` (compile / fit / evaluate / predict / save) over the engine.
+
+The reference drives training through `tf.keras.Model.compile/fit/evaluate`
+(`resnet_imagenet_main.py:199-259`).  This class keeps that calling convention
+and the callback protocol while the work underneath is done by an executor
+(native HIP engine on MI355X, PyTorch reference elsewhere), a distribution
+strategy (bucketed RCCL all-reduce or parameter-server push/pull) and a fused
+optimizer over flat buffers.
+
+Per training step:  callbacks.on_batch_begin -> next batch -> forward + backward
+(gradient buckets are all-reduced while backward is still running) -> fused
+SGD-momentum(+L2, +loss-scale, +1/replicas) -> metric accumulation on the device
+(no host sync) -> callbacks.on_batch_end.
+"""
+from __future__ import annotations
+
+import math
+import sys
+import time
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from ..engine.params import ParamStore
+from ..engine.torch_executor import TorchExecutor
+from ..models.graph import ModelSpec
+from ..utils import logging
+from .callbacks import Callback, CallbackList, History
+from .optimizers import LossScaleOptimizer, Optimizer
+
+__all__ = ["Model", "SUPPORTED_LOSSES"]
+
+SUPPORTED_LOSSES = ("sparse_categorical_crossentropy", "categorical_crossentropy")
+
+
+def _pick_executor_kind(requested: str, device: torch.device, dtype: str) -> str:
+  if requested != "auto":
+    return requested
+  if device.type == "cuda" and dtype in ("bf16", "bfloat16"):
+    return "hip"
+  return "torch"
+
+
+class Model:
+  """A model replica bound to a device, an executor and (optionally) a strategy."""
+
+  def __init__(self, spec: ModelSpec, strategy=None, dtype: str = "fp32",
+               device: Optional[torch.device] = None, seed: int = 0,
+               executor: str = "auto", data_format: str = "channels_last"):
+    self.spec = spec
+    self.name = spec.name
+    self.strategy = strategy
+    self.dtype = {"float32": "fp32", "bfloat16": "bf16", "float16": "fp16"}.get(dtype, dtype)
+    if device is None:
+      if strategy is not None:
+        device = strategy.device
+      else:
+        device = torch.device("cpu")
+    self.device = torch.device(device)
+    self.data_format = data_format
+    self.store = ParamStore(spec, self.device, seed)
+    self.executor_kind = _pick_executor_kind(executor, self.device, self.dtype)
+    self._executors: Dict[int, object] = {}
+    self.optimizer: Optional[Optimizer] = None
+    self.loss: Optional[str] = None
+    self.metrics_names: List[str] = ["loss"]
+    self._acc_name: Optional[str] = None
+    self.stop_training = False
+    self._reducer = None
+    self._buckets = None
+    self._synced_initial = False
+    self.history: Optional[History] = None
+
+  # -- configuration -----------------------------------------------------------------
+  def compile(self, optimizer: Optimizer, loss: str = "sparse_categorical_crossentropy",
+              metrics: Optional[Sequence[str]] = None, run_eagerly=None,
+              experimental_run_tf_function=None):
+    del run_eagerly, experimental_run_tf_function   # accepted for call-site parity
+    if loss not in SUPPORTED_LOSSES:
+      raise ValueError("loss must be one of %s" % (SUPPORTED_LOSSES,))
+    self.optimizer = optimizer
+    self.loss = loss
+    self._acc_name = None
+    for m in metrics or []:
+      if m in ("sparse_categorical_accuracy", "categorical_accuracy", "accuracy", "acc"):
+        self._acc_name = m if m.endswith("accuracy") and m != "accuracy" else (
+            "sparse_categorical_accuracy" if loss.startswith("sparse") else
+            "categorical_accuracy")
+      else:
+        raise ValueError("unsupported metric %r" % m)
+    self.metrics_names = ["loss"] + ([self._acc_name] if self._acc_name else [])
+    for s in optimizer.slot_names:
+      self.store.slot(s)
+
+  # -- executors ---------------------------------------------------------------------
+  def _bucket_list(self):
+    if self._buckets is None:
+      st = self.strategy
+      hv = getattr(self.optimizer, "fusion_bytes", None)
+      if hv is not None:
+        self._buckets = self.store.make_buckets(bucket_bytes=hv)
+      elif st is not None and getattr(st, "bucket_bytes", None):
+        self._buckets = self.store.make_buckets(bucket_bytes=st.bucket_bytes)
+      else:
+        self._buckets = self.store.make_buckets(
+            num_packs=getattr(st, "num_packs", 1) if st is not None else 1)
+    return self._buckets
+
+  def _executor(self, batch: int):
+    ex = self._executors.get(batch)
+    if ex is None:
+      if self.executor_kind == "hip":
+        from ..engine.hip_executor import HipExecutor  # pylint: disable=import-outside-toplevel
+        ex = HipExecutor(self.spec, self.store, batch, self.dtype, self._bucket_list())
+      else:
+        ex = TorchExecutor(self.spec, self.store, batch, self.dtype, self._bucket_list())
+      self._executors[batch] = ex
+    return ex
+
+  def _grad_reducer(self):
+    if self._reducer is None:
+      mk = getattr(self.optimizer, "make_reducer", None)       # hvd.DistributedOptimizer
+      if mk is not None:
+        self._reducer = mk(self.store, self._bucket_list()) or False
+      elif self.strategy is not None:
+        self._reducer = self.strategy.make_reducer(self.store, self._bucket_list()) or False
+      else:
+        self._reducer = False
+    return self._reducer or None
+
+  def synchronize(self):
+    if self.device.type == "cuda":
+      torch.cuda.synchronize(self.device)
+
+  def _sync_initial_variables(self):
+    if not self._synced_initial and self.strategy is not None:
+      self.strategy.broadcast_variables(self.store, 0)
+      for ex in self._executors.values():
+        ex.params_updated()
+    self._synced_initial = True
+
+  # -- label handling -----------------------------------------------------------------
+  def _class_indices(self, labels: torch.Tensor) -> torch.Tensor:
+    if self.loss == "categorical_crossentropy":
+      if labels.dim() != 2:
+        raise ValueError("categorical_crossentropy expects one-hot labels [N, classes]")
+      return labels.argmax(dim=1).long()
+    return labels.reshape(-1).long()
+
+  # -- one step ---------------------------------------------------------------------
+  def _loss_scale(self) -> float:
+    return self.optimizer.loss_scale if isinstance(self.optimizer, LossScaleOptimizer) else 1.0
+
+  def train_on_batch(self, images: torch.Tensor, labels: torch.Tensor):
+    """Runs one optimisation step; returns (mean loss tensor, correct-count tensor)."""
+    st = self.strategy
+    ex = self._executor(int(images.shape[0]))
+    idx = self._class_indices(labels.to(self.device))
+    if st is not None and not st.synchronous:
+      # asynchronous parameter server: pull -> compute -> push
+      st.pull(self.store)
+      ex.params_updated()
+      scale = self._loss_scale()
+      loss, correct = ex.train_step(images, idx, scale)
+      st.push(self.store, self.optimizer.current_lr(), scale)
+      self.optimizer.iterations += 1
+      return loss, correct
+    red = self._grad_reducer()
+    loss, correct = ex.train_step(images, idx, self._loss_scale(),
+                                  red.on_bucket_ready if red is not None else None)
+    if red is not None:
+      red.finish()
+    self.optimizer.apply_gradients(self.store, red.divisor if red is not None else 1.0, ex)
+    return loss, correct
+
+  def test_on_batch(self, images, labels):
+    ex = self._executor(int(images.shape[0]))
+    return ex.eval_step(images, self._class_indices(labels.to(self.device)))
+
+  # -- fit ---------------------------------------------------------------------------
+  def fit(self, x: Iterable, epochs: int = 1, steps_per_epoch: Optional[int] = None,
+          callbacks: Optional[List[Callback]] = None, validation_data: Optional[Iterable] = None,
+          validation_steps: Optional[int] = None, validation_freq: int = 1,
+          verbose: int = 1, initial_epoch: int = 0) -> History:
+    if self.optimizer is None:
+      raise RuntimeError("compile() the model before fit()")
+    st = self.strategy
+    history = History()
+    self.history = history
+    if st is not None and st.is_ps_task:
+      # A parameter-server task does not train: it serves until every worker is done.
+      st.serve(self)
+      return history
+    if steps_per_epoch is None:
+      steps_per_epoch = len(x)  # type: ignore[arg-type]
+    cbs = CallbackList([history] + list(callbacks or []), self,
+                       dict(epochs=epochs, steps=steps_per_epoch, verbose=verbose))
+    self._sync_initial_variables()
+    self.stop_training = False
+    it = iter(x)
+    cbs.call("on_train_begin", None)
+    acc = torch.zeros(3, dtype=torch.float64, device=self.device)  # loss_sum, correct, count
+    for epoch in range(initial_epoch, epochs):
+      cbs.call("on_epoch_begin", epoch, None)
+      acc.zero_()
+      t_epoch = time.time()
+      if verbose:
+        print("Epoch %d/%d" % (epoch + 1, epochs), flush=True)
+      for step in range(steps_per_epoch):
+        cbs.call("on_batch_begin", step, None)
+        images, labels = next(it)
+        n = int(images.shape[0])
+        loss, correct = self.train_on_batch(images, labels)
+        acc[0] += loss.double() * n
+        acc[1] += correct.double()
+        acc[2] += n
+        logs = {"batch": step, "size": n}
+        if cbs.wants_batch_logs or (verbose == 1 and self._progress_due(step, steps_per_epoch)):
+          vals = acc.tolist()
+          logs["loss"] = vals[0] / max(vals[2], 1)
+          if self._acc_name:
+            logs[self._acc_name] = vals[1] / max(vals[2], 1)
+          if verbose == 1:
+            self._print_progress(step, steps_per_epoch, logs, t_epoch)
+        cbs.call("on_batch_end", step, logs)
+        if self.stop_training:
+          break
+      logs = self._epoch_logs(acc)
+      if validation_data is not None and (epoch + 1) % max(validation_freq, 1) == 0:
+        val = self.evaluate(validation_data, steps=validation_steps, verbose=0)
+        logs["val_loss"] = val[0]
+        if self._acc_name:
+          logs["val_" + self._acc_name] = val[1]
+      if verbose:
+        dt = time.time() - t_epoch
+        print("%d/%d - %.0fs - %s" % (steps_per_epoch, steps_per_epoch, dt, " - ".join(
+            "%s: %.4f" % (k, v) for k, v in logs.items())), flush=True)
+      cbs.call("on_epoch_end", epoch, logs)
+      if self.stop_training:
+        break
+    cbs.call("on_train_end", None)
+    return history
+
+  @staticmethod
+  def _progress_due(step, total):
+    every = max(total // 20, 1)
+    return (step + 1) % every == 0 or step + 1 == total
+
+  def _print_progress(self, step, total, logs, t0):
+    dt = time.time() - t0
+    msg = " - ".join("%s: %.4f" % (k, v) for k, v in logs.items() if k not in ("batch", "size"))
+    print("%5d/%d - %.0fs - %s" % (step + 1, total, dt, msg), flush=True)
+
+  def _epoch_logs(self, acc: torch.Tensor) -> Dict[str, np.floating]:
+    st = self.strategy
+    if st is not None and st.synchronous and st.num_replicas_in_sync > 1:
+      acc = st.reduce_scalars(acc.clone())
+    vals = acc.tolist()
+    count = max(vals[2], 1.0)
+    reg = float(self.store.regularization_loss().item())
+    logs = {"loss": np.float64(vals[0] / count + reg)}
+    if self._acc_name:
+      logs[self._acc_name] = np.float64(vals[1] / count)
+    return logs
+
+  # -- evaluate / predict ----------------------------------------------------------------
+  def evaluate(self, x: Iterable, steps: Optional[int] = None, verbose: int = 0):
+    """Returns `[loss, accuracy]` (numpy scalars), like Keras with one metric."""
+    st = self.strategy
+    if st is not None and st.is_ps_task:
+      return None
+    if st is not None and not st.synchronous:
+      st.pull(self.store)
+      for ex in self._executors.values():
+        ex.params_updated()
+    self._sync_initial_variables()
+    if steps is None:
+      steps = len(x)  # type: ignore[arg-type]
+    acc = torch.zeros(3, dtype=torch.float64, device=self.device)
+    it = iter(x)
+    for _ in range(steps):
+      images, labels = next(it)
+      n = int(images.shape[0])
+      loss, correct = self.test_on_batch(images, labels)
+      acc[0] += loss.double() * n
+      acc[1] += correct.double()
+      acc[2] += n
+    if st is not None and st.synchronous and st.num_replicas_in_sync > 1:
+      acc = st.reduce_scalars(acc)
+    vals = acc.tolist()
+    count = max(vals[2], 1.0)
+    reg = float(self.store.regularization_loss().item())
+    out = [np.float64(vals[0] / count + reg), np.float64(vals[1] / count)]
+    if verbose:
+      print("%d/%d - loss: %.4f - %s: %.4f" % (steps, steps, out[0],
+                                               self._acc_name or "accuracy", out[1]), flush=True)
+    return out if self._acc_name else [out[0]]
+
+  def predict(self, images: torch.Tensor) -> torch.Tensor:
+    ex = self._executor(int(images.shape[0]))
+    return ex.predict(images)
+
+  __call__ = predict
+
+  # -- weights ---------------------------------------------------------------------------
+  def count_params(self) -> int:
+    return self.spec.count_params()
+
+  def get_weights(self) -> Dict[str, torch.Tensor]:
+    return self.store.get_weights()
+
+  def set_weights(self, weights, strict: bool = True):
+    self.store.set_weights(weights, strict)
+    for ex in self._executors.values():
+      ex.params_updated()
+
+  def save_weights(self, path: str):
+    from ..checkpoint import keras_h5  # pylint: disable=import-outside-toplevel
+    keras_h5.save_model(path, self, include_optimizer=False)
+
+  def save(self, path: str, include_optimizer: bool = True):
+    from ..checkpoint import keras_h5  # pylint: disable=import-outside-toplevel
+    keras_h5.save_model(path, self, include_optimizer=include_optimizer)
+
+  def load_weights(self, path: str, load_optimizer: bool = True):
+    from ..checkpoint import keras_h5  # pylint: disable=import-outside-toplevel
+    keras_h5.load_model(path, self, load_optimizer=load_optimizer)
+    for ex in self._executors.values():
+      ex.params_updated()
+    self._synced_initial = False   # a restored rank 0 must be re-broadcast
+
+  def summary(self, print_fn=print):
+    print_fn('Model: "%s"' % self.name)
+    for op in self.spec.ops:
+      print_fn("  %-28s %-8s -> %s" % (op.name, op.kind, self.spec.shapes[op.output]))
+    print_fn("Total params: %d (trainable %d)" % (
+        self.spec.count_params(), self.spec.count_params(True)))

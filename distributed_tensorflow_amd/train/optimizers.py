@@ -1,0 +1,168 @@
+"""Optimizers over the flat variable buffers.
+
+`SGD` reproduces the Keras momentum rule the reference uses
+(`common.py:169-172`, `gradient_descent_v2.SGD(lr, momentum=0.9)`):
+
+    v <- momentum * v - lr * g          (learning rate *inside* the velocity)
+    w <- w + v
+
+with the gradient `g = grad / grad_divisor + 2*lambda*w` where the second term
+is the derivative of the L2 regulariser `lambda * sum(w^2)` Keras attaches to
+conv kernels, the dense kernel and the dense bias (`resnet_model.py:42-43,377-379`)
+but not to BatchNorm scale/offset.  On a GPU with the native extension the
+whole update is one fused multi-tensor HIP kernel; otherwise a handful of torch
+ops over the flat buffers.
+
+`LossScaleOptimizer` adds static or dynamic loss scaling
+(`resnet_imagenet_main.py:182-187`): gradients arrive multiplied by the scale,
+are unscaled inside the update, and with dynamic scaling a non-finite gradient
+skips the step and halves the scale, while 2000 clean steps double it.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Optional, Union
+
+import torch
+
+from ..engine.params import ParamStore
+
+__all__ = ["SGD", "LossScaleOptimizer", "Optimizer"]
+
+Schedule = Union[float, Callable[[int], float]]
+
+
+class Optimizer:
+  """Base class: holds `learning_rate` (float or schedule) and `iterations`."""
+
+  def __init__(self, learning_rate: Schedule = 0.01):
+    self._lr = learning_rate
+    self.iterations = 0
+
+  @property
+  def learning_rate(self):
+    return self._lr
+
+  @learning_rate.setter
+  def learning_rate(self, value):
+    self._lr = value
+
+  lr = learning_rate
+
+  def current_lr(self) -> float:
+    lr = self._lr
+    if callable(lr):
+      lr = lr(self.iterations)
+    return float(lr)
+
+  def apply_gradients(self, store: ParamStore, grad_divisor: float = 1.0,
+                      executor=None) -> bool:  # pragma: no cover - interface
+    raise NotImplementedError
+
+  # Slots the optimizer keeps in the store (for checkpoints / broadcast).
+  slot_names = ()
+
+  def get_config(self):
+    return {"name": type(self).__name__, "learning_rate": self.current_lr()}
+
+
+class SGD(Optimizer):
+  """Keras-form SGD with (non-Nesterov) momentum and fused L2."""
+
+  slot_names = ("momentum",)
+
+  def __init__(self, learning_rate: Schedule = 0.01, momentum: float = 0.0,
+               nesterov: bool = False):
+    super().__init__(learning_rate)
+    if nesterov:
+      raise NotImplementedError("the reference uses plain momentum")
+    self.momentum = float(momentum)
+
+  def apply_gradients(self, store: ParamStore, grad_divisor: float = 1.0,
+                      executor=None) -> bool:
+    lr = self.current_lr()
+    from ..ops import fused  # pylint: disable=import-outside-toplevel
+    v = store.slot("momentum") if self.momentum else store.params  # unused when momentum == 0
+    fused.sgd_momentum_l2(store.params, store.grads, v, store.l2_vector(), lr,
+                          self.momentum, 1.0 / grad_divisor)
+    store.version += 1
+    if executor is not None:
+      executor.params_updated()
+    self.iterations += 1
+    return True
+
+  def get_config(self):
+    c = super().get_config()
+    c.update(momentum=self.momentum, nesterov=False)
+    return c
+
+
+class LossScaleOptimizer(Optimizer):
+  """Wraps an optimizer with a static or dynamic loss scale."""
+
+  def __init__(self, inner: Optimizer, loss_scale: Union[float, str] = "dynamic",
+               initial_scale: float = 2.0 ** 15, growth_steps: int = 2000,
+               multiplier: float = 2.0):
+    self.inner = inner
+    self.dynamic = loss_scale == "dynamic"
+    self.scale = float(initial_scale if self.dynamic else loss_scale)
+    self.growth_steps = growth_steps
+    self.multiplier = multiplier
+    self._good_steps = 0
+    self.skipped_steps = 0
+
+  # learning-rate plumbing goes to the wrapped optimizer
+  @property
+  def learning_rate(self):
+    return self.inner.learning_rate
+
+  @learning_rate.setter
+  def learning_rate(self, v):
+    self.inner.learning_rate = v
+
+  lr = learning_rate
+
+  @property
+  def iterations(self):
+    return self.inner.iterations
+
+  @iterations.setter
+  def iterations(self, v):
+    self.inner.iterations = v
+
+  @property
+  def slot_names(self):
+    return self.inner.slot_names
+
+  @property
+  def momentum(self):
+    return getattr(self.inner, "momentum", 0.0)
+
+  def current_lr(self):
+    return self.inner.current_lr()
+
+  @property
+  def loss_scale(self) -> float:
+    return self.scale
+
+  def apply_gradients(self, store: ParamStore, grad_divisor: float = 1.0,
+                      executor=None) -> bool:
+    if self.dynamic:
+      finite = bool(torch.isfinite(store.grads).all().item())
+      if not finite:
+        self.scale = max(self.scale / self.multiplier, 1.0)
+        self._good_steps = 0
+        self.skipped_steps += 1
+        return False
+    ok = self.inner.apply_gradients(store, grad_divisor * self.scale, executor)
+    if self.dynamic:
+      self._good_steps += 1
+      if self._good_steps >= self.growth_steps:
+        self.scale *= self.multiplier
+        self._good_steps = 0
+    return ok
+
+  def get_config(self):
+    c = self.inner.get_config()
+    c.update(loss_scale="dynamic" if self.dynamic else self.scale)
+    return c
