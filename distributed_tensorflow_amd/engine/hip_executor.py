@@ -1,0 +1,498 @@
+"""Native MI355X executor: compiles a `ModelSpec` into a plan of hand-written HIP kernels.
+
+Planning happens once per (model, batch size): every activation, gradient, statistic and
+packed-weight buffer is allocated up front (288 GB of HBM3E per GPU means nothing is
+recomputed and nothing is freed during training), tile configurations are chosen per layer
+shape, and every kernel launch of the forward and backward pass is recorded into a native
+`Plan` with its final device addresses.  A training step is then
+
+    copy batch into the staging buffers -> plan.run(forward) -> plan.run(backward segment 0)
+    -> bucket 0 ready (all-reduce starts on the communication stream) -> segment 1 -> ...
+
+i.e. a handful of C++ calls that enqueue a few hundred kernels on the HIP stream; with no
+gradient reducer the whole step can be captured once and replayed as a single hipGraph.
+
+Kernel inventory per layer kind:
+
+* conv / dense forward and data gradient: `conv_igemm.hip` (implicit GEMM on MFMA, also the
+  four-parity decomposition of strided data gradients);
+* conv / dense weight gradient: `conv_wgrad.hip` (split-K, transposing LDS reads, fp32 atomics
+  straight into the flat gradient bucket, Keras HWIO layout);
+* BatchNorm(+add)(+ReLU): `bn.hip`; max / mean pooling: `pool.hip`; loss: `loss.hip`;
+  optimizer, weight repacking, input preprocessing: `optim.hip`.
+
+Mixed precision: bf16 activations and packed weights, fp32 master weights, fp32 accumulation,
+statistics, loss and gradient buffers (`resnet_imagenet_main.py:97-100` keeps fp32 variables
+the same way for fp16).
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from ..models.graph import ModelSpec, Op
+from ..ops import native
+from ..ops.conv_plan import ConvGeom, round_up
+from ..utils import logging
+from .params import Bucket, ParamStore
+
+__all__ = ["HipExecutor", "supports"]
+
+
+def supports(spec: ModelSpec) -> bool:
+  """True when every op of the model has a native kernel path."""
+  for op in spec.ops:
+    if op.kind not in ("conv", "bn", "maxpool", "mean", "dense"):
+      return False
+    if op.kind == "dense" and op.attrs["in_features"] % 8:
+      return False
+    if op.kind == "bn":
+      c = op.attrs["channels"]
+      if c < 8 or c > 2048 or c & (c - 1):
+        return False
+  return True
+
+
+class HipExecutor:
+  native = True
+
+  def __init__(self, spec: ModelSpec, store: ParamStore, batch_size: int, dtype: str = "bf16",
+               buckets: Optional[List[Bucket]] = None, use_graph: Optional[bool] = None):
+    if store.device.type != "cuda":
+      raise RuntimeError("HipExecutor needs a GPU device")
+    if dtype not in ("bf16", "bfloat16"):
+      raise ValueError("the native engine computes in bf16 (got %s)" % dtype)
+    if not supports(spec):
+      raise ValueError("model %s contains ops without a native kernel" % spec.name)
+    native.ext()   # raises if the extension is missing: no silent fallback on the GPU
+    self.spec = spec
+    self.store = store
+    self.N = int(batch_size)
+    self.device = store.device
+    self.buckets = buckets if buckets is not None else store.make_buckets(1)
+    if use_graph is None:
+      use_graph = os.environ.get("DTF_HIP_GRAPH", "1") != "0"
+    self.use_graph = use_graph
+    self._keep: List[torch.Tensor] = []      # owns every planned buffer
+    self._graph_stream: Optional[torch.cuda.Stream] = None
+    self._train_graph = None
+    self._pool_idx: Dict[str, torch.Tensor] = {}
+    self._seen_version = -1
+    with torch.cuda.device(self.device):
+      self._plan_model()
+
+  # ----------------------------------------------------------------------------------------
+  # buffers
+  # ----------------------------------------------------------------------------------------
+  def _alloc(self, shape, dtype=torch.bfloat16, zero=True) -> torch.Tensor:
+    t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+    self._keep.append(t)
+    return t
+
+  def _var_ptr(self, name: str, which: str = "value") -> int:
+    return self.store.view(name, which).data_ptr()
+
+  # ----------------------------------------------------------------------------------------
+  # planning
+  # ----------------------------------------------------------------------------------------
+  def _plan_model(self):
+    spec, N = self.spec, self.N
+    H, W, C = spec.input_shape
+    self.images = self._alloc((N, H, W, C), torch.float32)
+    self.labels = self._alloc((N,), torch.int32)
+    self.accum = self._alloc((2,), torch.float32)            # [loss sum, correct count]
+    self.loss_scale_dev = self._alloc((1,), torch.float32)
+    self.loss_scale_dev.fill_(1.0)
+    self._loss_scale = 1.0
+
+    # ---- first pass: geometry of every layer, activation tensors -------------------------
+    acts: Dict[str, torch.Tensor] = {}
+    self.acts = acts
+    geoms: Dict[str, ConvGeom] = {}
+    self.geoms = geoms
+    first_conv = next((o for o in spec.ops if o.kind == "conv"), None)
+    consumers: Dict[str, int] = {}
+    for op in spec.ops:
+      for t in op.inputs:
+        consumers[t] = consumers.get(t, 0) + 1
+
+    # input staging for the first convolution
+    if first_conv is None or first_conv.inputs[0] != "input":
+      raise ValueError("native engine expects the model to start with a convolution")
+    a = first_conv.attrs
+    merged = a["cin"] <= 4 and a["kw"] <= 8 and a["stride"] % 2 == 0
+    g0 = ConvGeom(N, H, W, a["cin"], a["kh"], a["kw"], a["cout"], a["stride"], tuple(a["pad"]),
+                  mode="merged" if merged else "normal")
+    geoms[first_conv.name] = g0
+    acts["input"] = self._alloc(g0.input_shape)
+    self._pre = dict(N=N, H=H, W=W, Cin=C, pt=a["pad"][0] if merged else 0,
+                     pl=a["pad"][2] if merged else 0, OH=g0.Hs, OW=g0.Ws, Cpad=g0.Cs)
+    self._pre["in"] = self.images.data_ptr()
+    self._pre["out"] = acts["input"].data_ptr()
+
+    shapes = spec.shapes
+    for op in spec.ops:
+      at = op.attrs
+      if op.kind == "conv":
+        if op.name not in geoms:
+          h, w, c = shapes[op.inputs[0]]
+          geoms[op.name] = ConvGeom(N, h, w, c, at["kh"], at["kw"], at["cout"], at["stride"],
+                                    tuple(at["pad"]))
+        acts[op.output] = self._alloc(geoms[op.name].output_shape)
+      elif op.kind == "dense":
+        geoms[op.name] = ConvGeom(N, 1, 1, at["in_features"], 1, 1, at["out_features"])
+        acts[op.output] = self._alloc((N, geoms[op.name].ldc))
+      elif op.kind in ("bn", "maxpool"):
+        ho, wo, c = shapes[op.output]
+        acts[op.output] = self._alloc((N, ho, wo, c))
+      elif op.kind == "mean":
+        acts[op.output] = self._alloc((N, shapes[op.output][0]))
+
+    # ---- packed weights ------------------------------------------------------------------
+    self._plan_weight_packing()
+
+    # ---- BatchNorm side buffers -------------------------------------------------------------
+    bn_ops = [o for o in spec.ops if o.kind == "bn"]
+    tot = sum(o.attrs["channels"] for o in bn_ops)
+    self.bn_stats = self._alloc((2 * max(tot, 1),), torch.float32)    # [sum | sqsum] per layer
+    self.bn_saved = self._alloc((2 * max(tot, 1),), torch.float32)    # [mean | invstd] per layer
+    bn_off: Dict[str, int] = {}
+    o = 0
+    for b in bn_ops:
+      bn_off[b.name] = o
+      o += 2 * b.attrs["channels"]
+    self._bn_off = bn_off
+
+    ext = native.ext()
+    self.fwd_plan = ext.Plan()
+    self.eval_plan = ext.Plan()
+    self.bwd_plan = ext.Plan()
+    self._build_forward(self.fwd_plan, training=True)
+    self._build_forward(self.eval_plan, training=False)
+    self._build_backward(consumers)
+    self.probs = None
+    nbytes = sum(t.numel() * t.element_size() for t in self._keep)
+    logging.info("HipExecutor planned %s for batch %d: %d fwd + %d bwd launches, %.2f GB of "
+                 "buffers, %d gradient buckets", spec.name, N, self.fwd_plan.size(),
+                 self.bwd_plan.size(), nbytes / 2 ** 30, len(self.buckets))
+
+  def _plan_weight_packing(self):
+    """bf16 copies of every conv / dense kernel: forward layout and data-gradient layout."""
+    descs = []
+    off = 0
+    self._wf: Dict[str, int] = {}     # op name -> element offset of the forward copy
+    self._wd: Dict[str, int] = {}     # op name -> element offset of the dgrad copy
+    first = True
+    for op in self.spec.ops:
+      if op.kind not in ("conv", "dense"):
+        continue
+      g = self.geoms[op.name]
+      e = self.store.entries[op.name + "/kernel"]
+      d = g.pack_fwd()
+      d.update(src_off=e.offset, dst_off=off)
+      self._wf[op.name] = off
+      off += round_up(d["count"], 8)
+      descs.append(d)
+      needs_dgrad = not (first and op.kind == "conv")
+      first = False
+      if needs_dgrad:
+        d = g.pack_dgrad()
+        d.update(src_off=e.offset, dst_off=off)
+        self._wd[op.name] = off
+        off += round_up(d["count"], 8)
+        descs.append(d)
+    blk = 0
+    for d in descs:
+      d["first_block"] = blk
+      blk += -(-d["count"] // native.PACK_PER_BLOCK)
+    self.packed = self._alloc((off,), torch.bfloat16)
+    raw = native.pack_desc_bytes(descs)
+    self.pack_descs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+    self._keep.append(self.pack_descs)
+    self._pack_args = dict(params=self.store.params.data_ptr(), packed=self.packed.data_ptr(),
+                           descs=self.pack_descs.data_ptr(), ndesc=len(descs), nblocks=blk)
+
+  def _wf_ptr(self, name):
+    return self.packed.data_ptr() + 2 * self._wf[name]
+
+  def _wd_ptr(self, name):
+    return self.packed.data_ptr() + 2 * self._wd[name]
+
+  # ---- forward ---------------------------------------------------------------------------
+  def _build_forward(self, plan, training: bool):
+    spec, N = self.spec, self.N
+    acts = self.acts
+    if training:
+      plan.add("memset", dict(ptr=self.bn_stats.data_ptr(), nbytes=self.bn_stats.numel() * 4),
+               "zero_bn_stats")
+    plan.add("memset", dict(ptr=self.accum.data_ptr(), nbytes=8), "zero_loss")
+    plan.add("preprocess_pad", self._pre, "preprocess")
+    for op in spec.ops:
+      at = op.attrs
+      x = acts[op.inputs[0]]
+      if op.kind == "conv":
+        g = self.geoms[op.name]
+        plan.add("conv", g.fwd(x.data_ptr(), self._wf_ptr(op.name), acts[op.output].data_ptr()),
+                 op.name)
+      elif op.kind == "dense":
+        g = self.geoms[op.name]
+        plan.add("conv", g.fwd(x.data_ptr(), self._wf_ptr(op.name), acts[op.output].data_ptr(),
+                               bias=self._var_ptr(op.name + "/bias")), op.name)
+      elif op.kind == "bn":
+        C = at["channels"]
+        P = x.numel() // C
+        so = self._bn_off[op.name]
+        sum_p = self.bn_stats.data_ptr() + 4 * so
+        sq_p = sum_p + 4 * C
+        mean_p = self.bn_saved.data_ptr() + 4 * so
+        inv_p = mean_p + 4 * C
+        if training:
+          plan.add("bn_stats", dict(y=x.data_ptr(), sum=sum_p, sqsum=sq_p, P=P, C=C),
+                   op.name + "/stats")
+        res = acts[op.inputs[1]].data_ptr() if len(op.inputs) > 1 else None
+        plan.add("bn_apply", dict(
+            y=x.data_ptr(), res=res, z=acts[op.output].data_ptr(), sum=sum_p, sqsum=sq_p,
+            gamma=self._var_ptr(op.name + "/gamma"), beta=self._var_ptr(op.name + "/beta"),
+            mm=self._var_ptr(op.name + "/moving_mean"),
+            mv=self._var_ptr(op.name + "/moving_variance"), save_mean=mean_p, save_invstd=inv_p,
+            P=P, C=C, eps=float(at["eps"]), momentum=float(at["momentum"]),
+            relu=int(at["relu"]), training=int(training)), op.name)
+      elif op.kind == "maxpool":
+        h, w, c = spec.shapes[op.inputs[0]]
+        ho, wo, _ = spec.shapes[op.output]
+        if op.name not in self._pool_idx:
+          self._pool_idx[op.name] = self._alloc((N, ho, wo, c), torch.uint8)
+        plan.add("maxpool_fwd", dict(x=x.data_ptr(), out=acts[op.output].data_ptr(),
+                                     idx=self._pool_idx[op.name].data_ptr(), N=N, H=h, W=w, C=c,
+                                     OH=ho, OW=wo, k=at["k"], stride=at["stride"],
+                                     pt=at["pad"][0], pl=at["pad"][2]), op.name)
+      elif op.kind == "mean":
+        plan.add("mean_fwd", dict(x=x.data_ptr(), out=acts[op.output].data_ptr(), N=N,
+                                  HW=at["h"] * at["w"], C=at["channels"]), op.name)
+    logits = acts[spec.logits_name]
+    ld = logits.shape[1]
+    if training:
+      self.dlogits = self._alloc((N, ld))
+    plan.add("softmax_xent", dict(
+        logits=logits.data_ptr(), labels=self.labels.data_ptr(),
+        dlogits=self.dlogits.data_ptr() if training else None, accum=self.accum.data_ptr(),
+        N=N, C=spec.num_classes, ld=ld, grad_scale=1.0 / N,
+        grad_scale_dev=self.loss_scale_dev.data_ptr()), "softmax_xent")
+
+  # ---- backward ----------------------------------------------------------------------------
+  def _build_backward(self, consumers: Dict[str, int]):
+    spec, N = self.spec, self.N
+    acts = self.acts
+    plan = self.bwd_plan
+    grads: Dict[str, torch.Tensor] = {spec.logits_name: self.dlogits}
+    written = {spec.logits_name}
+    self.act_grads = grads
+
+    def grad_buf(name: str) -> torch.Tensor:
+      if name not in grads:
+        grads[name] = self._alloc(tuple(acts[name].shape), zero=False)
+      return grads[name]
+
+    # which bucket a variable belongs to, and how many variables each bucket still waits for
+    var_bucket: Dict[str, int] = {}
+    remaining: Dict[int, int] = {}
+    for b in self.buckets:
+      remaining[b.index] = len(b.var_names)
+      for v in b.var_names:
+        var_bucket[v] = b.index
+    self._segments: List[Tuple[int, int, List[Bucket]]] = []
+    seg_begin = 0
+    by_index = {b.index: b for b in self.buckets}
+
+    def done(vars_: List[str]):
+      nonlocal seg_begin
+      ready = []
+      for v in vars_:
+        bi = var_bucket[v]
+        remaining[bi] -= 1
+        if remaining[bi] == 0:
+          ready.append(by_index[bi])
+      if ready:
+        self._segments.append((seg_begin, plan.size(), ready))
+        seg_begin = plan.size()
+
+    plan.add("memset", dict(ptr=self.store.grads.data_ptr(),
+                            nbytes=self.store.grads.numel() * 4), "zero_grads")
+    first_conv = next(o for o in spec.ops if o.kind == "conv")
+    for op in reversed(spec.ops):
+      at = op.attrs
+      xname = op.inputs[0]
+      dout = grads.get(op.output)
+      if dout is None:
+        raise RuntimeError("no gradient reaches %s" % op.output)
+      if op.kind == "dense":
+        g = self.geoms[op.name]
+        plan.add("colsum", dict(x=dout.data_ptr(), out=self._var_ptr(op.name + "/bias", "grad"),
+                                N=N, C=g.Cout, ld=g.ldc), op.name + "/dbias")
+        plan.add("wgrad", g.wgrad(acts[xname].data_ptr(), dout.data_ptr(),
+                                  self._var_ptr(op.name + "/kernel", "grad")), op.name + "/wgrad")
+        dx = grad_buf(xname)
+        for d in g.dgrad(dout.data_ptr(), self._wd_ptr(op.name), dx.data_ptr(),
+                         accumulate=xname in written):
+          plan.add("conv", d, op.name + "/dgrad")
+        written.add(xname)
+        done([op.name + "/kernel", op.name + "/bias"])
+      elif op.kind == "mean":
+        dx = grad_buf(xname)
+        if xname in written:
+          raise RuntimeError("mean-pool input with several consumers is not planned")
+        plan.add("mean_bwd", dict(dy=dout.data_ptr(), dx=dx.data_ptr(), N=N,
+                                  HW=at["h"] * at["w"], C=at["channels"]), op.name + "/bwd")
+        written.add(xname)
+      elif op.kind == "maxpool":
+        h, w, c = spec.shapes[xname]
+        ho, wo, _ = spec.shapes[op.output]
+        dx = grad_buf(xname)
+        if xname in written:
+          raise RuntimeError("max-pool input with several consumers is not planned")
+        plan.add("maxpool_bwd", dict(dy=dout.data_ptr(), idx=self._pool_idx[op.name].data_ptr(),
+                                     dx=dx.data_ptr(), N=N, H=h, W=w, C=c, OH=ho, OW=wo,
+                                     k=at["k"], stride=at["stride"], pt=at["pad"][0],
+                                     pl=at["pad"][2]), op.name + "/bwd")
+        written.add(xname)
+      elif op.kind == "bn":
+        C = at["channels"]
+        x = acts[xname]
+        P = x.numel() // C
+        so = self._bn_off[op.name]
+        mean_p = self.bn_saved.data_ptr() + 4 * so
+        inv_p = mean_p + 4 * C
+        if xname in written:
+          raise RuntimeError("BatchNorm input with several consumers is not planned")
+        dy = grad_buf(xname)
+        dres = None
+        if len(op.inputs) > 1:
+          rname = op.inputs[1]
+          if rname in written:
+            raise RuntimeError("residual gradient must be the first writer of %s" % rname)
+          dres = grad_buf(rname).data_ptr()
+          written.add(rname)
+        plan.add("bn_bwd", dict(
+            dz=dout.data_ptr(), y=x.data_ptr(),
+            z=acts[op.output].data_ptr() if at["relu"] else None, mean=mean_p, invstd=inv_p,
+            gamma=self._var_ptr(op.name + "/gamma"),
+            dgamma=self._var_ptr(op.name + "/gamma", "grad"),
+            dbeta=self._var_ptr(op.name + "/beta", "grad"), dy=dy.data_ptr(), dres=dres,
+            P=P, C=C), op.name + "/bwd")
+        written.add(xname)
+        done([op.name + "/gamma", op.name + "/beta"])
+      elif op.kind == "conv":
+        g = self.geoms[op.name]
+        plan.add("wgrad", g.wgrad(acts[xname].data_ptr(), dout.data_ptr(),
+                                  self._var_ptr(op.name + "/kernel", "grad")), op.name + "/wgrad")
+        if op is not first_conv:
+          dx = grad_buf(xname)
+          for d in g.dgrad(dout.data_ptr(), self._wd_ptr(op.name), dx.data_ptr(),
+                           accumulate=xname in written):
+            plan.add("conv", d, op.name + "/dgrad")
+          written.add(xname)
+        done([op.name + "/kernel"])
+    if seg_begin < plan.size() or not self._segments:
+      self._segments.append((seg_begin, plan.size(), []))
+    left = [i for i, r in remaining.items() if r]
+    if left:
+      raise RuntimeError("buckets never completed: %s" % left)
+
+  # ----------------------------------------------------------------------------------------
+  # execution
+  # ----------------------------------------------------------------------------------------
+  def params_updated(self):
+    """Refresh the packed bf16 weights from the fp32 master copy (one multi-tensor launch)."""
+    native.run_op("pack_weights", self._pack_args)
+    self._seen_version = self.store.version
+
+  def _ensure_packed(self):
+    if self._seen_version != self.store.version:
+      self.params_updated()
+
+  def _stage(self, images: torch.Tensor, labels: Optional[torch.Tensor]):
+    if tuple(images.shape) != tuple(self.images.shape):
+      raise ValueError("HipExecutor planned for input %s, got %s"
+                       % (tuple(self.images.shape), tuple(images.shape)))
+    if images.data_ptr() != self.images.data_ptr():
+      self.images.copy_(images, non_blocking=True)
+    if labels is not None:
+      self.labels.copy_(labels.reshape(-1), non_blocking=True)
+
+  def _set_loss_scale(self, s: float):
+    if s != self._loss_scale:
+      self.loss_scale_dev.fill_(float(s))
+      self._loss_scale = float(s)
+
+  def train_step(self, images: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0,
+                 on_bucket_ready: Optional[Callable[[Bucket], None]] = None
+                 ) -> Tuple[torch.Tensor, torch.Tensor]:
+    with torch.cuda.device(self.device):
+      self._ensure_packed()
+      self._stage(images, labels)
+      self._set_loss_scale(loss_scale)
+      if on_bucket_ready is None and self.use_graph:
+        self._run_train_graph()
+      else:
+        s = native.stream_handle(self.device)
+        self.fwd_plan.run(0, self.fwd_plan.size(), s)
+        for begin, end, ready in self._segments:
+          self.bwd_plan.run(begin, end, s)
+          if on_bucket_ready is not None:
+            for b in ready:
+              on_bucket_ready(b)
+      out = self.accum.clone()
+    return out[0] / self.N, out[1]
+
+  def _run_train_graph(self):
+    """Forward + backward as one hipGraph (captured at first use on a side stream)."""
+    cur = torch.cuda.current_stream(self.device)
+    if self._train_graph is None:
+      if self._graph_stream is None:
+        self._graph_stream = torch.cuda.Stream(self.device)
+      gs = self._graph_stream
+      gs.wait_stream(cur)
+      with torch.cuda.stream(gs):
+        # one eager run first: lazy module loading must not happen under capture
+        s = native.stream_handle(self.device)
+        self.fwd_plan.run(0, self.fwd_plan.size(), s)
+        self.bwd_plan.run(0, self.bwd_plan.size(), s)
+        gs.synchronize()
+        h1 = self.fwd_plan.capture(0, self.fwd_plan.size(), s)
+        h2 = self.bwd_plan.capture(0, self.bwd_plan.size(), s)
+        self._train_graph = (h1, h2)
+      cur.wait_stream(gs)
+      # The eager run above updated the BatchNorm moving averages once; it is the first
+      # training step's forward, so fall through to replay only from the next call on.
+      return
+    s = int(cur.cuda_stream)
+    self.fwd_plan.replay(self._train_graph[0], s)
+    self.bwd_plan.replay(self._train_graph[1], s)
+
+  @torch.no_grad()
+  def eval_step(self, images: torch.Tensor, labels: torch.Tensor):
+    with torch.cuda.device(self.device):
+      self._ensure_packed()
+      self._stage(images, labels)
+      self.eval_plan.run(0, self.eval_plan.size(), native.stream_handle(self.device))
+      out = self.accum.clone()
+    return out[0] / self.N, out[1]
+
+  @torch.no_grad()
+  def predict(self, images: torch.Tensor) -> torch.Tensor:
+    with torch.cuda.device(self.device):
+      self._ensure_packed()
+      self._stage(images, None)
+      self.eval_plan.run(0, self.eval_plan.size(), native.stream_handle(self.device))
+      logits = self.acts[self.spec.logits_name]
+      probs = torch.empty((self.N, self.spec.num_classes), dtype=torch.float32,
+                          device=self.device)
+      native.run_op("softmax_probs", dict(logits=logits.data_ptr(), probs=probs.data_ptr(),
+                                          N=self.N, C=self.spec.num_classes,
+                                          ld=logits.shape[1]))
+    return probs
+
+  def synchronize(self):
+    torch.cuda.synchronize(self.device)

@@ -1,0 +1,312 @@
+// Python bindings and the launch-plan executor of the native engine.
+//
+// The Python side plans a model once (shapes, tile configurations, buffer addresses) and
+// records every kernel launch of a training step into a `Plan`.  Running a step is then a
+// single call that enqueues the recorded launches on a HIP stream with no per-kernel Python
+// or dispatcher overhead; any contiguous range of the plan can also be captured into a
+// hipGraph and replayed with one `hipGraphLaunch`.
+//
+// Every op is described by a (kind, args-dict) pair.  The same description either runs
+// immediately (`run_op`, used by the unit tests and one-off calls) or is appended to a plan
+// (`Plan.add`).  Tensor arguments are raw device addresses (Python ints from
+// `tensor.data_ptr()`); the Python wrapper owns the tensors and keeps them alive.
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "conv_params.h"
+#include "elementwise.h"
+
+namespace py = pybind11;
+using Launch = std::function<void(hipStream_t)>;
+
+namespace {
+
+template <typename T>
+T get(const py::dict& d, const char* key) {
+  if (!d.contains(key)) throw std::invalid_argument(std::string("missing argument '") + key + "'");
+  return d[key].cast<T>();
+}
+template <typename T>
+T get_or(const py::dict& d, const char* key, T dflt) {
+  if (!d.contains(key) || d[key].is_none()) return dflt;
+  return d[key].cast<T>();
+}
+template <typename T>
+T* ptr(const py::dict& d, const char* key, bool required = true) {
+  if (!d.contains(key) || d[key].is_none()) {
+    if (required) throw std::invalid_argument(std::string("missing tensor '") + key + "'");
+    return nullptr;
+  }
+  return reinterpret_cast<T*>(d[key].cast<uintptr_t>());
+}
+
+ConvParams conv_from_dict(const py::dict& d) {
+  ConvParams p;
+  p.in = ptr<const bf16_t>(d, "in");
+  p.wgt = ptr<const bf16_t>(d, "wgt");
+  p.out = ptr<bf16_t>(d, "out");
+  p.addend = ptr<const bf16_t>(d, "addend", false);
+  p.bias = ptr<const float>(d, "bias", false);
+  p.N = get<int>(d, "N"); p.H = get<int>(d, "H"); p.W = get<int>(d, "W");
+  p.Cpix = get<int>(d, "Cpix");
+  p.OH = get<int>(d, "OH"); p.OW = get<int>(d, "OW");
+  p.M = p.N * p.OH * p.OW;
+  p.OHfull = get_or<int>(d, "OHfull", p.OH); p.OWfull = get_or<int>(d, "OWfull", p.OW);
+  p.Cout = get<int>(d, "Cout");
+  p.ldc = get_or<int>(d, "ldc", p.Cout);
+  p.OSH = get_or<int>(d, "OSH", 1); p.OSW = get_or<int>(d, "OSW", 1);
+  p.OOH = get_or<int>(d, "OOH", 0); p.OOW = get_or<int>(d, "OOW", 0);
+  p.TI = get<int>(d, "TI"); p.TJ = get<int>(d, "TJ");
+  p.Ctap = get<int>(d, "Ctap");
+  p.Ktotal = p.TI * p.TJ * p.Ctap;
+  p.ISH = get_or<int>(d, "ISH", 1); p.ISW = get_or<int>(d, "ISW", 1);
+  p.dh0 = get_or<int>(d, "dh0", 0); p.dhs = get_or<int>(d, "dhs", 1);
+  p.dw0 = get_or<int>(d, "dw0", 0); p.dws = get_or<int>(d, "dws", 1);
+  p.ldw = get<int>(d, "ldw");
+  p.wk0 = get_or<int>(d, "wk0", 0);
+  p.wsi = get_or<int>(d, "wsi", p.TJ * p.Ctap);
+  p.wsj = get_or<int>(d, "wsj", p.Ctap);
+  p.divOW = make_fastdiv((uint32_t)p.OW);
+  p.divOH = make_fastdiv((uint32_t)p.OH);
+  return p;
+}
+
+WgradParams wgrad_from_dict(const py::dict& d) {
+  WgradParams p;
+  p.x = ptr<const bf16_t>(d, "x");
+  p.dy = ptr<const bf16_t>(d, "dy");
+  p.dw = ptr<float>(d, "dw");
+  p.N = get<int>(d, "N"); p.H = get<int>(d, "H"); p.W = get<int>(d, "W");
+  p.Cpix = get<int>(d, "Cpix");
+  p.OH = get<int>(d, "OH"); p.OW = get<int>(d, "OW");
+  p.P = p.N * p.OH * p.OW;
+  p.Cout = get<int>(d, "Cout");
+  p.ldy = get_or<int>(d, "ldy", p.Cout);
+  p.TI = get<int>(d, "TI"); p.TJ = get<int>(d, "TJ");
+  p.Ctap = get<int>(d, "Ctap");
+  p.Ktotal = p.TI * p.TJ * p.Ctap;
+  p.ISH = get_or<int>(d, "ISH", 1); p.ISW = get_or<int>(d, "ISW", 1);
+  p.dh0 = get_or<int>(d, "dh0", 0); p.dhs = get_or<int>(d, "dhs", 1);
+  p.dw0 = get_or<int>(d, "dw0", 0); p.dws = get_or<int>(d, "dws", 1);
+  p.Cpad = get_or<int>(d, "Cpad", p.Ctap);
+  p.Creal = get_or<int>(d, "Creal", p.Cpad);
+  p.TJpad = get_or<int>(d, "TJpad", p.TJ);
+  p.TJreal = get_or<int>(d, "TJreal", p.TJpad);
+  p.splits = get_or<int>(d, "splits", 1);
+  int pps = (p.P + p.splits - 1) / p.splits;
+  pps = ((pps + 31) / 32) * 32;
+  p.pix_per_split = pps;
+  p.divOW = make_fastdiv((uint32_t)p.OW);
+  p.divOH = make_fastdiv((uint32_t)p.OH);
+  p.divCpad = make_fastdiv((uint32_t)p.Cpad);
+  p.divTJpad = make_fastdiv((uint32_t)p.TJpad);
+  return p;
+}
+
+Launch make_op(const std::string& kind, const py::dict& d) {
+  if (kind == "conv") {
+    const ConvParams p = conv_from_dict(d);
+    const int cfg = get_or<int>(d, "cfg", 0);
+    return [p, cfg](hipStream_t s) { launch_conv_igemm(p, cfg, s); };
+  }
+  if (kind == "wgrad") {
+    const WgradParams p = wgrad_from_dict(d);
+    const int cfg = get_or<int>(d, "cfg", 0);
+    return [p, cfg](hipStream_t s) { launch_conv_wgrad(p, cfg, s); };
+  }
+  if (kind == "bn_stats") {
+    auto y = ptr<const bf16_t>(d, "y"); auto sum = ptr<float>(d, "sum");
+    auto sq = ptr<float>(d, "sqsum");
+    const int P = get<int>(d, "P"), C = get<int>(d, "C");
+    return [=](hipStream_t s) { launch_bn_stats(y, sum, sq, P, C, s); };
+  }
+  if (kind == "bn_apply") {
+    auto y = ptr<const bf16_t>(d, "y"); auto res = ptr<const bf16_t>(d, "res", false);
+    auto z = ptr<bf16_t>(d, "z");
+    auto sum = ptr<const float>(d, "sum", false); auto sq = ptr<const float>(d, "sqsum", false);
+    auto gamma = ptr<const float>(d, "gamma"); auto beta = ptr<const float>(d, "beta");
+    auto mm = ptr<float>(d, "mm"); auto mv = ptr<float>(d, "mv");
+    auto smean = ptr<float>(d, "save_mean", false); auto sinv = ptr<float>(d, "save_invstd", false);
+    const int P = get<int>(d, "P"), C = get<int>(d, "C");
+    const float eps = get<float>(d, "eps"), mom = get<float>(d, "momentum");
+    const int relu = get<int>(d, "relu"), training = get<int>(d, "training");
+    if (training && (!sum || !sq || !smean || !sinv))
+      throw std::invalid_argument("bn_apply: training needs sum/sqsum/save_mean/save_invstd");
+    return [=](hipStream_t s) {
+      launch_bn_apply(y, res, z, sum, sq, gamma, beta, mm, mv, smean, sinv, P, C, eps, mom, relu,
+                      training, s);
+    };
+  }
+  if (kind == "bn_bwd") {
+    auto dz = ptr<const bf16_t>(d, "dz"); auto y = ptr<const bf16_t>(d, "y");
+    auto z = ptr<const bf16_t>(d, "z", false);
+    auto mean = ptr<const float>(d, "mean"); auto inv = ptr<const float>(d, "invstd");
+    auto gamma = ptr<const float>(d, "gamma");
+    auto dgamma = ptr<float>(d, "dgamma"); auto dbeta = ptr<float>(d, "dbeta");
+    auto dy = ptr<bf16_t>(d, "dy"); auto dres = ptr<bf16_t>(d, "dres", false);
+    const int P = get<int>(d, "P"), C = get<int>(d, "C");
+    return [=](hipStream_t s) {
+      launch_bn_bwd(dz, y, z, mean, inv, gamma, dgamma, dbeta, dy, dres, P, C, s);
+    };
+  }
+  if (kind == "maxpool_fwd" || kind == "maxpool_bwd") {
+    const int N = get<int>(d, "N"), H = get<int>(d, "H"), W = get<int>(d, "W"), C = get<int>(d, "C");
+    const int OH = get<int>(d, "OH"), OW = get<int>(d, "OW"), k = get<int>(d, "k");
+    const int st = get<int>(d, "stride"), pt = get<int>(d, "pt"), pl = get<int>(d, "pl");
+    auto idx = ptr<uint8_t>(d, "idx");
+    if (kind == "maxpool_fwd") {
+      auto x = ptr<const bf16_t>(d, "x"); auto out = ptr<bf16_t>(d, "out");
+      return [=](hipStream_t s) { launch_maxpool_fwd(x, out, idx, N, H, W, C, OH, OW, k, st, pt, pl, s); };
+    }
+    auto dy = ptr<const bf16_t>(d, "dy"); auto dx = ptr<bf16_t>(d, "dx");
+    return [=](hipStream_t s) { launch_maxpool_bwd(dy, idx, dx, N, H, W, C, OH, OW, k, st, pt, pl, s); };
+  }
+  if (kind == "mean_fwd") {
+    auto x = ptr<const bf16_t>(d, "x"); auto out = ptr<bf16_t>(d, "out");
+    const int N = get<int>(d, "N"), HW = get<int>(d, "HW"), C = get<int>(d, "C");
+    return [=](hipStream_t s) { launch_global_mean_fwd(x, out, N, HW, C, s); };
+  }
+  if (kind == "mean_bwd") {
+    auto dy = ptr<const bf16_t>(d, "dy"); auto dx = ptr<bf16_t>(d, "dx");
+    const int N = get<int>(d, "N"), HW = get<int>(d, "HW"), C = get<int>(d, "C");
+    return [=](hipStream_t s) { launch_global_mean_bwd(dy, dx, N, HW, C, s); };
+  }
+  if (kind == "softmax_xent") {
+    auto logits = ptr<const bf16_t>(d, "logits"); auto labels = ptr<const int32_t>(d, "labels");
+    auto dl = ptr<bf16_t>(d, "dlogits", false); auto acc = ptr<float>(d, "accum");
+    const int N = get<int>(d, "N"), C = get<int>(d, "C"), ld = get<int>(d, "ld");
+    // grad_scale may change per step (dynamic loss scale): an optional device scalar carries it.
+    const float gs = get_or<float>(d, "grad_scale", 1.f);
+    auto gsd = ptr<const float>(d, "grad_scale_dev", false);   // multiplies grad_scale
+    return [=](hipStream_t s) { launch_softmax_xent(logits, labels, dl, acc, N, C, ld, gs, gsd, s); };
+  }
+  if (kind == "softmax_probs") {
+    auto logits = ptr<const bf16_t>(d, "logits"); auto probs = ptr<float>(d, "probs");
+    const int N = get<int>(d, "N"), C = get<int>(d, "C"), ld = get<int>(d, "ld");
+    return [=](hipStream_t s) { launch_softmax_probs(logits, probs, N, C, ld, s); };
+  }
+  if (kind == "colsum") {
+    auto x = ptr<const bf16_t>(d, "x"); auto out = ptr<float>(d, "out");
+    const int N = get<int>(d, "N"), C = get<int>(d, "C"), ld = get<int>(d, "ld");
+    return [=](hipStream_t s) { launch_colsum(x, out, N, C, ld, s); };
+  }
+  if (kind == "sgd") {
+    auto p = ptr<float>(d, "p"); auto g = ptr<const float>(d, "g"); auto v = ptr<float>(d, "v");
+    auto l2 = ptr<const float>(d, "l2x2");
+    const size_t n = get<size_t>(d, "n");
+    const float lr = get_or<float>(d, "lr", 0.f), mom = get_or<float>(d, "momentum", 0.f);
+    const float gs = get_or<float>(d, "grad_scale", 1.f);
+    auto hyper = ptr<const float>(d, "hyper", false);   // device [lr, momentum, grad_scale]
+    const int um = get_or<int>(d, "use_momentum", mom != 0.f ? 1 : 0);
+    return [=](hipStream_t s) { launch_sgd_momentum_l2(p, g, v, l2, n, lr, mom, gs, um, hyper, s); };
+  }
+  if (kind == "pack_weights") {
+    auto params = ptr<const float>(d, "params"); auto packed = ptr<bf16_t>(d, "packed");
+    auto descs = ptr<const PackDesc>(d, "descs");
+    const int nd = get<int>(d, "ndesc"), nb = get<int>(d, "nblocks");
+    return [=](hipStream_t s) { launch_pack_weights(params, packed, descs, nd, nb, s); };
+  }
+  if (kind == "preprocess_pad") {
+    auto in = ptr<const float>(d, "in"); auto out = ptr<bf16_t>(d, "out");
+    const int N = get<int>(d, "N"), H = get<int>(d, "H"), W = get<int>(d, "W");
+    const int Cin = get<int>(d, "Cin"), pt = get<int>(d, "pt"), pl = get<int>(d, "pl");
+    const int OH = get<int>(d, "OH"), OW = get<int>(d, "OW"), Cpad = get<int>(d, "Cpad");
+    return [=](hipStream_t s) { launch_preprocess_pad(in, out, N, H, W, Cin, pt, pl, OH, OW, Cpad, s); };
+  }
+  if (kind == "cast_bf16") {
+    auto in = ptr<const float>(d, "in"); auto out = ptr<bf16_t>(d, "out");
+    const size_t n = get<size_t>(d, "n");
+    return [=](hipStream_t s) { launch_cast_f32_bf16(in, out, n, s); };
+  }
+  if (kind == "memset") {
+    auto p = ptr<uint8_t>(d, "ptr");
+    const size_t n = get<size_t>(d, "nbytes");
+    const int value = get_or<int>(d, "value", 0);
+    return [=](hipStream_t s) { HIP_CHECK(hipMemsetAsync(p, value, n, s)); };
+  }
+  throw std::invalid_argument("unknown op kind '" + kind + "'");
+}
+
+void check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) throw std::runtime_error(std::string("kernel launch failed: ") + hipGetErrorString(e));
+}
+
+class Plan {
+ public:
+  ~Plan() {
+    for (auto& g : graphs_) {
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
+      if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+  }
+  int add(const std::string& kind, const py::dict& args, const std::string& name) {
+    ops_.push_back(make_op(kind, args));
+    names_.push_back(name.empty() ? kind : name);
+    return (int)ops_.size() - 1;
+  }
+  int size() const { return (int)ops_.size(); }
+  std::string name(int i) const { return names_.at(i); }
+  void run(int begin, int end, uintptr_t stream) {
+    if (begin < 0 || end > (int)ops_.size() || begin > end) throw std::out_of_range("Plan.run range");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (int i = begin; i < end; ++i) ops_[i](s);
+    check_launch();
+  }
+  // Captures ops [begin, end) on `stream` into a hipGraph; returns a handle for replay().
+  int capture(int begin, int end, uintptr_t stream) {
+    if (begin < 0 || end > (int)ops_.size() || begin > end) throw std::out_of_range("Plan.capture range");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    Graph g;
+    HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    try {
+      for (int i = begin; i < end; ++i) ops_[i](s);
+    } catch (...) {
+      hipGraph_t tmp = nullptr;
+      (void)hipStreamEndCapture(s, &tmp);
+      if (tmp) (void)hipGraphDestroy(tmp);
+      throw;
+    }
+    HIP_CHECK(hipStreamEndCapture(s, &g.graph));
+    HIP_CHECK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+    graphs_.push_back(g);
+    return (int)graphs_.size() - 1;
+  }
+  void replay(int handle, uintptr_t stream) {
+    HIP_CHECK(hipGraphLaunch(graphs_.at(handle).exec, reinterpret_cast<hipStream_t>(stream)));
+  }
+
+ private:
+  struct Graph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+  std::vector<Launch> ops_;
+  std::vector<std::string> names_;
+  std::vector<Graph> graphs_;
+};
+
+}  // namespace
+
+PYBIND11_MODULE(_dtf_native, m) {
+  m.doc() = "gfx950 (MI355X) kernels and launch-plan executor";
+  m.def("run_op", [](const std::string& kind, const py::dict& args, uintptr_t stream) {
+    make_op(kind, args)(reinterpret_cast<hipStream_t>(stream));
+    check_launch();
+  }, py::arg("kind"), py::arg("args"), py::arg("stream") = 0);
+  m.def("fastdiv_check", [](uint32_t n, uint32_t d) { return fd_div(n, make_fastdiv(d)); });
+  m.def("pack_desc_size", []() { return (int)sizeof(PackDesc); });
+  m.attr("PACK_PER_BLOCK") = 256 * 8;
+  m.attr("arch") = "gfx950";
+  py::class_<Plan>(m, "Plan")
+      .def(py::init<>())
+      .def("add", &Plan::add, py::arg("kind"), py::arg("args"), py::arg("name") = "")
+      .def("size", &Plan::size)
+      .def("name", &Plan::name)
+      .def("run", &Plan::run, py::arg("begin"), py::arg("end"), py::arg("stream") = 0)
+      .def("capture", &Plan::capture)
+      .def("replay", &Plan::replay);
+}

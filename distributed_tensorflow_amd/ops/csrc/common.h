@@ -1,0 +1,95 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) kernels.
+//
+// Conventions used by every kernel in this directory:
+//  * activations are NHWC bf16 (raw uint16_t bits), accumulation and statistics are fp32;
+//  * a wavefront has 64 lanes; blocks are 256 threads = 4 waves, one per SIMD of a CU;
+//  * matrix work goes through v_mfma_f32_16x16x32_bf16 (A: lane l holds row l&15,
+//    k = 8*(l>>4)..+7; B: lane l holds column l&15, same k; C/D: column l&15,
+//    rows 4*(l>>4)..+3 in the four result registers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;   // 16-byte load/store unit
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define DTF_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+
+// Round-to-nearest-even conversion; lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaNs.
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, h);
+}
+
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+  u32x4 v;
+  v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
+  v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Unsigned division by a run-time constant with a precomputed multiplier
+// (q = (n * mul) >> 32 >> shift); exact for n < 2^31. Built on the host by make_fastdiv().
+struct FastDiv {
+  uint32_t d, mul, shift;
+};
+
+__host__ __device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv& f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.shift);
+#else
+  return f.d == 1 ? n : (uint32_t)((((uint64_t)n * f.mul) >> 32) >> f.shift);
+#endif
+}
+
+static inline FastDiv make_fastdiv(uint32_t d) {
+  // l = ceil(log2 d), mul = ceil(2^(31+l) / d) < 2^32, q = umulhi(n, mul) >> (l - 1).
+  // mul*d - 2^(31+l) < d <= 2^l, which makes the quotient exact for every n < 2^31.
+  FastDiv f;
+  f.d = d;
+  if (d <= 1) { f.mul = 0; f.shift = 0; f.d = 1; return f; }
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  uint64_t p2 = 1ull << (31 + l);
+  f.mul = (uint32_t)((p2 + d - 1) / d);
+  f.shift = l - 1;
+  return f;
+}
+
+#define HIP_CHECK(expr)                                                            \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess)                                                          \
+      throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)

@@ -1,0 +1,360 @@
+// Implicit-GEMM NHWC convolution on MFMA (forward and data-gradient).
+//
+//   out[n, oh*OSH+OOH, ow*OSW+OOW, co] (+= addend) (+ bias[co]) =
+//       sum over taps (i, j) and channels c of
+//       in[n, oh*ISH + dh0 + i*dhs, ow*ISW + dw0 + j*dws, c] * wgt[co][wk0 + i*wsi + j*wsj + c]
+//
+// One kernel covers: forward convolution with TensorFlow SAME/VALID padding and
+// any stride; stride-1 data gradient (taps walked backwards over dY); stride-2
+// data gradient as four output-parity sub-problems (each a stride-1 gather with
+// a tap subset, written with output stride 2); 1x1 convolutions and the dense
+// layer (pure GEMM).  Out-of-image taps read zeros; `Cout` and `Ktotal` may be
+// ragged (dense layer: 1001 outputs).
+//
+// GEMM view: M = N*OH*OW pixels, N = Cout, K = taps*Ctap.  Block tile BM pixels x
+// BN channels x BK=32, 256 threads = 4 waves arranged WAVES_M x WAVES_N.  The MFMA
+// A operand is the *weight* tile and the B operand the *pixel* tile, so that a
+// lane ends up holding 4*NR consecutive output channels of one pixel and stores
+// them with 16-byte writes, no LDS transpose in the epilogue.
+//
+// Pipeline: register-staged double buffering.  While the MFMAs of K-step t run
+// from LDS buffer t&1, the global loads of step t+1 are already in flight into
+// registers; they are written to the other LDS buffer after the math and one
+// barrier closes the step.  LDS rows are 64 bytes (32 bf16 of K); the four
+// 16-byte chunks of a row are XOR-swizzled so that the ds_read_b128 fragment
+// reads of a 16-lane group land on 16 distinct 16-byte slots of the 256-byte
+// bank row.
+//
+// Blocks are numbered so that the BN-tiles of one pixel tile share `blockIdx % 8`
+// (the label of the XCD they are dispatched to): they re-read the same input
+// rows from that XCD's L2 instead of HBM.
+#include <stdexcept>
+#include <string>
+
+#include "common.h"
+#include "conv_params.h"
+
+namespace {
+
+constexpr int BK = 32;
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool POINTWISE>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int MR = WM / 16, NR = WN / 16;
+  constexpr int XV = BM / 64;                       // 16-byte pixel-tile vectors per thread
+  constexpr int WV = (BN + 63) / 64;                // 16-byte weight-tile vectors per thread
+  constexpr int XBYTES = BM * 64, WBYTES = BN * 64;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+  static_assert(BM % 64 == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
+
+  __shared__ __attribute__((aligned(16))) uint8_t smem[2 * (XBYTES + WBYTES)];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // ---- block -> tile, XCD aware --------------------------------------------------
+  const int tilesN = (p.Cout + BN - 1) / BN;
+  const int tilesM = (p.M + BM - 1) / BM;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int mt = (slot / tilesN) * 8 + xcd;
+  const int nt = slot % tilesN;
+  if (mt >= tilesM) return;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- per-thread load geometry ----------------------------------------------------
+  const int kv = tid & 3;          // which 8-element (16-byte) piece of the 32-wide K step
+  const int lrow = tid >> 2;       // 0..63
+  int xbase[XV];                   // POINTWISE: element offset of the pixel row; else pixel index base n*H*W
+  int xh[XV], xw[XV];              // base input coordinates (before the tap offset)
+#pragma unroll
+  for (int r = 0; r < XV; ++r) {
+    const int m = m0 + lrow + 64 * r;
+    if (POINTWISE) {
+      xbase[r] = (m < p.M) ? m : -1;
+      xh[r] = xw[r] = 0;
+    } else {
+      if (m < p.M) {
+        const uint32_t t = fd_div((uint32_t)m, p.divOW);
+        const int ow = m - (int)t * p.OW;
+        const uint32_t n = fd_div(t, p.divOH);
+        const int oh = (int)t - (int)n * p.OH;
+        xbase[r] = (int)n * p.H * p.W;
+        xh[r] = oh * p.ISH + p.dh0;
+        xw[r] = ow * p.ISW + p.dw0;
+      } else {
+        xbase[r] = 0;
+        xh[r] = -(1 << 28);       // fails every bounds check
+        xw[r] = 0;
+      }
+    }
+  }
+  // running decomposition of this thread's k index into (tap i, tap j, channel c)
+  int kc = kv * 8, ti = 0, tj = 0;
+  if (!POINTWISE) {
+    while (kc >= p.Ctap) { kc -= p.Ctap; if (++tj == p.TJ) { tj = 0; ++ti; } }
+  }
+  int kk = kv * 8;                 // flat k of this thread's vector in the current step
+
+  const bf16_t* __restrict__ gin = p.in;
+  const bf16_t* __restrict__ gw = p.wgt;
+
+  u32x4 xreg[XV], wreg[WV];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  auto load_tile = [&]() {
+    const bool kval = kk < p.Ktotal;
+#pragma unroll
+    for (int r = 0; r < XV; ++r) {
+      if (POINTWISE) {
+        const bool ok = kval && xbase[r] >= 0;
+        const size_t off = ok ? ((size_t)xbase[r] * p.Cpix + kk) : 0;
+        u32x4 v = *reinterpret_cast<const u32x4*>(gin + off);   // offset 0 is always readable
+        xreg[r] = ok ? v : zero4;
+      } else {
+        const int hi = xh[r] + ti * p.dhs;
+        const int wi = xw[r] + tj * p.dws;
+        const bool ok = kval && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        const size_t off = ok ? ((size_t)(xbase[r] + hi * p.W + wi) * p.Cpix + kc) : 0;
+        u32x4 v = *reinterpret_cast<const u32x4*>(gin + off);
+        xreg[r] = ok ? v : zero4;
+      }
+    }
+    const int wk = POINTWISE ? (p.wk0 + kk) : (p.wk0 + ti * p.wsi + tj * p.wsj + kc);
+#pragma unroll
+    for (int r = 0; r < WV; ++r) {
+      const int row = lrow + 64 * r;
+      const int co = n0 + row;
+      const bool ok = kval && row < BN && co < p.Cout;
+      const size_t off = ok ? ((size_t)co * p.ldw + wk) : 0;
+      u32x4 v = *reinterpret_cast<const u32x4*>(gw + off);
+      wreg[r] = ok ? v : zero4;
+    }
+  };
+  auto advance_k = [&]() {
+    kk += BK;
+    if (!POINTWISE) {
+      kc += BK;
+      while (kc >= p.Ctap) { kc -= p.Ctap; if (++tj == p.TJ) { tj = 0; ++ti; } }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    uint8_t* xs = smem + buf * (XBYTES + WBYTES);
+    uint8_t* ws = xs + XBYTES;
+#pragma unroll
+    for (int r = 0; r < XV; ++r) {
+      const int row = lrow + 64 * r;
+      const int sw = (-(row >> 2)) & 3;
+      *reinterpret_cast<u32x4*>(xs + row * 64 + ((kv ^ sw) << 4)) = xreg[r];
+    }
+#pragma unroll
+    for (int r = 0; r < WV; ++r) {
+      const int row = lrow + 64 * r;
+      if (row < BN) {
+        const int sw = (-(row / (4 * NR))) & 3;
+        *reinterpret_cast<u32x4*>(ws + row * 64 + ((kv ^ sw) << 4)) = wreg[r];
+      }
+    }
+  };
+
+  // ---- fragment addresses (loop invariant) -------------------------------------------
+  const int fr = lane & 15, fq = lane >> 4;
+  int xoff[MR], woff[NR];
+#pragma unroll
+  for (int mr = 0; mr < MR; ++mr) {
+    const int row = wm * WM + mr * 16 + fr;
+    xoff[mr] = row * 64 + ((fq ^ ((-(row >> 2)) & 3)) << 4);
+  }
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr) {
+    // MFMA row fr = 4*q' + r' of tile nr carries output channel q'*(4*NR) + nr*4 + r'
+    const int row = wn * WN + (fr >> 2) * (4 * NR) + nr * 4 + (fr & 3);
+    woff[nr] = row * 64 + ((fq ^ ((-(row / (4 * NR))) & 3)) << 4);
+  }
+
+  f32x4 acc[NR][MR];
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) acc[nr][mr] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int KT = (p.Ktotal + BK - 1) / BK;
+  if (KT > 0) {
+    load_tile();
+    store_tile(0);
+    advance_k();
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < KT;
+    if (more) load_tile();                         // global loads in flight during the math
+    const uint8_t* xs = smem + buf * (XBYTES + WBYTES);
+    const uint8_t* ws = xs + XBYTES;
+    bf16x8 wf[NR], xf[MR];
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) wf[nr] = *reinterpret_cast<const bf16x8*>(ws + woff[nr]);
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) xf[mr] = *reinterpret_cast<const bf16x8*>(xs + xoff[mr]);
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr)
+        acc[nr][mr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nr], xf[mr], acc[nr][mr], 0, 0, 0);
+    if (more) {
+      store_tile(buf ^ 1);
+      advance_k();
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds 4*NR consecutive channels of pixel (mr, fr) ---------------------
+  constexpr int CPL = 4 * NR;                      // channels per lane
+  const int co0 = n0 + wn * WN + fq * CPL;
+  float bias[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c)
+    bias[c] = (p.bias != nullptr && co0 + c < p.Cout) ? p.bias[co0 + c] : 0.f;
+  const bool vec_ok = (p.ldc % 8 == 0);
+#pragma unroll
+  for (int mr = 0; mr < MR; ++mr) {
+    const int m = m0 + wm * WM + mr * 16 + fr;
+    if (m >= p.M) continue;
+    size_t obase;
+    if (POINTWISE) {
+      obase = (size_t)m * p.ldc;
+    } else {
+      const uint32_t t = fd_div((uint32_t)m, p.divOW);
+      const int ow = m - (int)t * p.OW;
+      const uint32_t n = fd_div(t, p.divOH);
+      const int oh = (int)t - (int)n * p.OH;
+      obase = ((size_t)((int)n * p.OHfull + oh * p.OSH + p.OOH) * p.OWfull +
+               (ow * p.OSW + p.OOW)) * p.ldc;
+    }
+    bf16_t* optr = p.out + obase + co0;
+    const bf16_t* aptr = p.addend ? p.addend + obase + co0 : nullptr;
+    if constexpr (CPL >= 8) {
+#pragma unroll
+      for (int h = 0; h < CPL / 8; ++h) {
+        // channels h*8 .. h*8+7 of this lane = MFMA tiles nr = 2h, 2h+1
+        float v0 = acc[2 * h][mr][0] + bias[h * 8 + 0], v1 = acc[2 * h][mr][1] + bias[h * 8 + 1];
+        float v2 = acc[2 * h][mr][2] + bias[h * 8 + 2], v3 = acc[2 * h][mr][3] + bias[h * 8 + 3];
+        float v4 = acc[2 * h + 1][mr][0] + bias[h * 8 + 4], v5 = acc[2 * h + 1][mr][1] + bias[h * 8 + 5];
+        float v6 = acc[2 * h + 1][mr][2] + bias[h * 8 + 6], v7 = acc[2 * h + 1][mr][3] + bias[h * 8 + 7];
+        if (vec_ok && co0 + h * 8 + 8 <= p.Cout) {
+          if (aptr) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(aptr + h * 8);
+            v0 += __uint_as_float(a.x << 16); v1 += __uint_as_float(a.x & 0xffff0000u);
+            v2 += __uint_as_float(a.y << 16); v3 += __uint_as_float(a.y & 0xffff0000u);
+            v4 += __uint_as_float(a.z << 16); v5 += __uint_as_float(a.z & 0xffff0000u);
+            v6 += __uint_as_float(a.w << 16); v7 += __uint_as_float(a.w & 0xffff0000u);
+          }
+          u32x4 o;
+          o.x = pack2bf(v0, v1); o.y = pack2bf(v2, v3); o.z = pack2bf(v4, v5); o.w = pack2bf(v6, v7);
+          *reinterpret_cast<u32x4*>(optr + h * 8) = o;
+        } else {
+          const float vv[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            if (co0 + h * 8 + c < p.Cout) {
+              float x = vv[c];
+              if (aptr) x += bf2f(aptr[h * 8 + c]);
+              optr[h * 8 + c] = f2bf(x);
+            }
+          }
+        }
+      }
+    } else {
+      // CPL == 4: one 8-byte store
+      float v0 = acc[0][mr][0] + bias[0], v1 = acc[0][mr][1] + bias[1];
+      float v2 = acc[0][mr][2] + bias[2], v3 = acc[0][mr][3] + bias[3];
+      if (p.ldc % 4 == 0 && co0 + 4 <= p.Cout) {
+        if (aptr) {
+          const u32x2 a = *reinterpret_cast<const u32x2*>(aptr);
+          v0 += __uint_as_float(a.x << 16); v1 += __uint_as_float(a.x & 0xffff0000u);
+          v2 += __uint_as_float(a.y << 16); v3 += __uint_as_float(a.y & 0xffff0000u);
+        }
+        u32x2 o;
+        o.x = pack2bf(v0, v1);
+        o.y = pack2bf(v2, v3);
+        *reinterpret_cast<u32x2*>(optr) = o;
+      } else {
+        const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (co0 + c < p.Cout) {
+            float x = vv[c];
+            if (aptr) x += bf2f(aptr[c]);
+            optr[c] = f2bf(x);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+void launch_cfg(const ConvParams& p, hipStream_t stream) {
+  const int tilesN = (p.Cout + BN - 1) / BN;
+  const int tilesM = (p.M + BM - 1) / BM;
+  const int grid = ((tilesM + 7) / 8) * 8 * tilesN;
+  const bool pointwise = p.TI == 1 && p.TJ == 1 && p.ISH == 1 && p.ISW == 1 && p.dh0 == 0 &&
+                         p.dw0 == 0 && p.OSH == 1 && p.OSW == 1 && p.OOH == 0 && p.OOW == 0 &&
+                         p.OH == p.H && p.OW == p.W && p.OHfull == p.OH && p.OWfull == p.OW &&
+                         p.Ctap <= p.Cpix;
+  if (pointwise)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, true>), dim3(grid), dim3(256),
+                       0, stream, p);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, false>), dim3(grid),
+                       dim3(256), 0, stream, p);
+}
+
+}  // namespace
+
+// Validates the descriptor on the host (a kernel that indexes out of bounds can take the
+// whole GPU down, so every shape assumption is checked before the launch).
+void validate_conv_params(const ConvParams& p) {
+  auto fail = [](const std::string& m) { throw std::invalid_argument("conv_igemm: " + m); };
+  if (!p.in || !p.wgt || !p.out) fail("null tensor pointer");
+  if (p.N <= 0 || p.H <= 0 || p.W <= 0 || p.OH <= 0 || p.OW <= 0) fail("bad spatial size");
+  if (p.M != p.N * p.OH * p.OW) fail("M != N*OH*OW");
+  if ((int64_t)p.N * p.H * p.W >= (1ll << 31) / 8) fail("input too large for 32-bit pixel index");
+  if (p.Ctap % 8 || p.Ctap <= 0) fail("Ctap must be a positive multiple of 8");
+  if (p.Ktotal != p.TI * p.TJ * p.Ctap) fail("Ktotal != TI*TJ*Ctap");
+  if (p.ldw % 8 || p.wk0 % 8 || p.wsi % 8 || p.wsj % 8) fail("weight offsets must be multiples of 8");
+  if (p.TI * p.TJ > 0 && p.wk0 + (p.TI - 1) * p.wsi + (p.TJ - 1) * p.wsj + p.Ctap > p.ldw)
+    fail("weight row overrun");
+  if (p.Cout <= 0 || p.ldc < p.Cout) fail("ldc < Cout");
+  if ((p.OH - 1) * p.OSH + p.OOH >= p.OHfull || (p.OW - 1) * p.OSW + p.OOW >= p.OWfull)
+    fail("output index overrun");
+  // every in-bounds pixel read must stay inside the input tensor: pixel*Cpix + Ctap <= total
+  if (p.Ctap > p.Cpix) {
+    // a tap that spans several pixels (stem): the last pixel of a row must leave room
+    const int span = (p.Ctap + p.Cpix - 1) / p.Cpix;
+    const int max_w = (p.OW - 1) * p.ISW + p.dw0 + (p.TJ - 1) * p.dws;
+    if (p.dws < 0 || p.dhs < 0 || p.dw0 < 0 || p.dh0 < 0) fail("multi-pixel taps need forward taps");
+    if (max_w + span > p.W) fail("multi-pixel tap overruns the input row");
+    if ((p.OH - 1) * p.ISH + p.dh0 + (p.TI - 1) * p.dhs >= p.H) fail("multi-pixel tap overruns H");
+    if ((p.Cpix * p.ISW) % 8 || (p.Cpix * p.W) % 8) fail("multi-pixel taps need 16-byte aligned rows");
+  } else if (p.Cpix % 8) {
+    fail("Cpix must be a multiple of 8");
+  }
+}
+
+void launch_conv_igemm(const ConvParams& p, int cfg, hipStream_t stream) {
+  validate_conv_params(p);
+  switch (cfg) {
+    case 0: launch_cfg<128, 128, 2, 2>(p, stream); break;
+    case 1: launch_cfg<256, 64, 4, 1>(p, stream); break;
+    case 2: launch_cfg<256, 32, 4, 1>(p, stream); break;
+    case 3: launch_cfg<256, 16, 4, 1>(p, stream); break;
+    case 4: launch_cfg<64, 128, 1, 4>(p, stream); break;
+    case 5: launch_cfg<128, 64, 2, 2>(p, stream); break;
+    default: throw std::invalid_argument("conv_igemm: unknown tile config");
+  }
+}

@@ -1,0 +1,43 @@
+// Descriptors of the implicit-GEMM convolution kernels (shared by kernels, launch plan and
+// Python bindings).
+#pragma once
+#include "common.h"
+
+// Forward / data-gradient gather GEMM; see conv_igemm.hip for the formula.
+struct ConvParams {
+  const bf16_t* in = nullptr;      // [N, H, W, Cpix]
+  const bf16_t* wgt = nullptr;     // packed [Cout][ldw], K contiguous
+  bf16_t* out = nullptr;           // [N, OHfull, OWfull, ldc]
+  const bf16_t* addend = nullptr;  // optional tensor added to the result (same layout as out)
+  const float* bias = nullptr;     // optional per-output-channel bias
+  int N = 0, H = 0, W = 0, Cpix = 0;
+  int OH = 0, OW = 0, M = 0;       // logical output grid; M = N*OH*OW
+  int OHfull = 0, OWfull = 0, ldc = 0;
+  int OSH = 1, OSW = 1, OOH = 0, OOW = 0;
+  int Cout = 0;
+  int TI = 1, TJ = 1, Ctap = 0, Ktotal = 0;
+  int ISH = 1, ISW = 1;
+  int dh0 = 0, dhs = 0, dw0 = 0, dws = 0;
+  int ldw = 0, wk0 = 0, wsi = 0, wsj = 0;
+  FastDiv divOW, divOH;
+};
+
+// Weight gradient: dW[k][co] += sum over pixels of X[pixel, k] * dY[pixel, co], where
+// k = (tap i, tap j, channel c) gathers X exactly like the forward pass.
+struct WgradParams {
+  const bf16_t* x = nullptr;       // forward input [N, H, W, Cpix]
+  const bf16_t* dy = nullptr;      // output gradient [N, OH, OW, ldy]
+  float* dw = nullptr;             // fp32 [TIr*TJr*Creal][Cout] (Keras HWIO), accumulated atomically
+  int N = 0, H = 0, W = 0, Cpix = 0;
+  int OH = 0, OW = 0, P = 0;       // P = N*OH*OW pixels (the reduction dimension)
+  int ldy = 0, Cout = 0;
+  int TI = 1, TJ = 1, Ctap = 0, Ktotal = 0;
+  int ISH = 1, ISW = 1, dh0 = 0, dhs = 1, dw0 = 0, dws = 1;
+  // epilogue decode of the padded k index into the real HWIO index
+  int Cpad = 0, Creal = 0, TJpad = 1, TJreal = 1;
+  int splits = 1, pix_per_split = 0;
+  FastDiv divOW, divOH, divCpad, divTJpad;
+};
+
+void launch_conv_igemm(const ConvParams& p, int cfg, hipStream_t stream);
+void launch_conv_wgrad(const WgradParams& p, int cfg, hipStream_t stream);

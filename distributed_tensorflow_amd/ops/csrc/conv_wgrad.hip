@@ -1,0 +1,260 @@
+// Weight gradient of the NHWC convolution on MFMA, split-K over pixels.
+//
+//   dW[k][co] += sum over pixels p of X[p, k] * dY[p, co],   k = (tap i, tap j, channel c)
+//
+// where X[p, k] is gathered from the forward input exactly as in the forward kernel.
+// GEMM view: M' = Ktotal (rows of dW), N' = Cout, reduction over P = N*OH*OW pixels,
+// which is huge (up to 3.2 M) - so the pixel range is split over gridDim.y blocks and the
+// partial tiles are combined with fp32 atomic adds into the (pre-zeroed) Keras-layout
+// HWIO gradient buffer, which is directly a slice of the flat all-reduce bucket.
+//
+// Both MFMA operands need the *reduction* index (pixel) contiguous per lane, but both
+// tensors are pixel-major in memory (channels contiguous).  The tiles are therefore staged
+// in LDS as [32 pixels][channels] exactly as they arrive (16-byte global loads, 16-byte LDS
+// stores) and read back with ds_read_b64_tr_b16, gfx950's transposing LDS read: each lane
+// gets 4 consecutive pixels of one channel per instruction, two reads form one 8-deep
+// MFMA operand.  The 32-byte column chunks of every LDS row are XOR-swizzled with a
+// function of the row so that the 8 rows touched by one 32-lane half fall into 8
+// distinct bank groups.
+#include <stdexcept>
+#include <string>
+
+#include "common.h"
+#include "conv_params.h"
+
+namespace {
+
+constexpr int BP = 32;  // pixels per reduction step
+
+typedef __attribute__((address_space(3))) short4v lds_short4;
+
+// Byte offset of 16-byte chunk `ch` of pixel row `row` inside a [32][WIDTH] bf16 tile.
+template <int WIDTH>
+__device__ __forceinline__ int tile_off(int row, int ch) {
+  if constexpr (WIDTH == 128) {
+    const int f = (row & 3) | (((row >> 3) & 1) << 2);
+    return row * 256 + ((((ch >> 1) ^ f) << 5) | ((ch & 1) << 4));
+  } else if constexpr (WIDTH == 64) {
+    const int f = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+    return row * 128 + ((((ch >> 1) ^ f) << 5) | ((ch & 1) << 4));
+  } else {
+    return row * (WIDTH * 2) + ch * 16;
+  }
+}
+
+// Transposed fragment: for the 16 channels starting at c0, lane (g = lane>>4, idx = lane&15)
+// receives pixels 8g..8g+7 of channel c0+idx.
+template <int WIDTH>
+__device__ __forceinline__ bf16x8 read_tr_frag(const uint8_t* tile, int c0, int lane) {
+  const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
+  const int ch = (c0 >> 3) + (pp >> 1);
+  const int sub = (pp & 1) << 3;
+  const uint8_t* a0 = tile + tile_off<WIDTH>(8 * g + q, ch) + sub;
+  const uint8_t* a1 = tile + tile_off<WIDTH>(8 * g + 4 + q, ch) + sub;
+  short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)a0);
+  short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)a1);
+  typedef __attribute__((ext_vector_type(8))) short short8v;
+  short8v r = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int BKK, int BCO, int WAVES_K, int WAVES_C, bool POINTWISE>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+  constexpr int WKK = BKK / WAVES_K, WCO = BCO / WAVES_C;
+  constexpr int KR = WKK / 16, CR = WCO / 16;
+  constexpr int XCPR = BKK / 8, YCPR = BCO / 8;                 // 16-byte chunks per tile row
+  constexpr int XRPP = 256 / XCPR, YRPP = 256 / YCPR;           // tile rows filled per pass
+  constexpr int XV = (BP + XRPP - 1) / XRPP, YV = (BP + YRPP - 1) / YRPP;
+  constexpr int XBYTES = BP * BKK * 2, YBYTES = BP * BCO * 2;
+  static_assert(WAVES_K * WAVES_C == 4, "4 waves per block");
+  static_assert(WKK % 16 == 0 && WCO % 16 == 0, "tile shape");
+
+  __shared__ __attribute__((aligned(16))) uint8_t smem[2 * (XBYTES + YBYTES)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / WAVES_C, wc = wave % WAVES_C;
+
+  const int tilesC = (p.Cout + BCO - 1) / BCO;
+  const int kt = blockIdx.x / tilesC, ct = blockIdx.x % tilesC;
+  const int k0 = kt * BKK, c0 = ct * BCO;
+  const int pbeg = blockIdx.y * p.pix_per_split;
+  const int pend = min(pbeg + p.pix_per_split, p.P);
+  if (pbeg >= pend) return;
+
+  // ---- X (input) gather geometry: this thread always loads the same 8 k-columns ----------
+  const int xch = tid % XCPR, xrow = tid / XCPR;
+  const int kcol = k0 + xch * 8;
+  const bool xk_ok = kcol < p.Ktotal;
+  int kc = 0, ti = 0, tj = 0;
+  if (!POINTWISE && xk_ok) {
+    const int t = kcol / p.Ctap;
+    kc = kcol - t * p.Ctap;
+    ti = t / p.TJ;
+    tj = t - ti * p.TJ;
+  }
+  const int tap_h = p.dh0 + ti * p.dhs, tap_w = p.dw0 + tj * p.dws;
+  // ---- dY geometry -------------------------------------------------------------------------
+  const int ych = tid % YCPR, yrow = tid / YCPR;
+  const int ycol = c0 + ych * 8;
+  const bool yc_ok = ycol < p.Cout;
+
+  const bf16_t* __restrict__ gx = p.x;
+  const bf16_t* __restrict__ gy = p.dy;
+  u32x4 xreg[XV], yreg[YV];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  auto load_tile = [&](int pstep) {
+#pragma unroll
+    for (int r = 0; r < XV; ++r) {
+      const int row = xrow + XRPP * r;
+      const int pp = pstep + row;
+      bool ok = xk_ok && row < BP && pp < pend;
+      size_t off = 0;
+      if (POINTWISE) {
+        off = ok ? ((size_t)pp * p.Cpix + kcol) : 0;
+      } else {
+        const uint32_t t = fd_div((uint32_t)(ok ? pp : 0), p.divOW);
+        const int ow = (ok ? pp : 0) - (int)t * p.OW;
+        const uint32_t n = fd_div(t, p.divOH);
+        const int oh = (int)t - (int)n * p.OH;
+        const int hi = oh * p.ISH + tap_h, wi = ow * p.ISW + tap_w;
+        ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        off = ok ? ((size_t)(((int)n * p.H + hi) * p.W + wi) * p.Cpix + kc) : 0;
+      }
+      const u32x4 v = *reinterpret_cast<const u32x4*>(gx + off);
+      xreg[r] = ok ? v : zero4;
+    }
+#pragma unroll
+    for (int r = 0; r < YV; ++r) {
+      const int row = yrow + YRPP * r;
+      const int pp = pstep + row;
+      const bool ok = yc_ok && row < BP && pp < pend;
+      const size_t off = ok ? ((size_t)pp * p.ldy + ycol) : 0;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(gy + off);
+      yreg[r] = ok ? v : zero4;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    uint8_t* xs = smem + buf * (XBYTES + YBYTES);
+    uint8_t* ys = xs + XBYTES;
+#pragma unroll
+    for (int r = 0; r < XV; ++r) {
+      const int row = xrow + XRPP * r;
+      if (row < BP) *reinterpret_cast<u32x4*>(xs + tile_off<BKK>(row, xch)) = xreg[r];
+    }
+#pragma unroll
+    for (int r = 0; r < YV; ++r) {
+      const int row = yrow + YRPP * r;
+      if (row < BP) *reinterpret_cast<u32x4*>(ys + tile_off<BCO>(row, ych)) = yreg[r];
+    }
+  };
+
+  f32x4 acc[KR][CR];
+#pragma unroll
+  for (int a = 0; a < KR; ++a)
+#pragma unroll
+    for (int b = 0; b < CR; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nsteps = (pend - pbeg + BP - 1) / BP;
+  load_tile(pbeg);
+  store_tile(0);
+  __syncthreads();
+
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    const bool more = s + 1 < nsteps;
+    if (more) load_tile(pbeg + (s + 1) * BP);
+    const uint8_t* xs = smem + buf * (XBYTES + YBYTES);
+    const uint8_t* ys = xs + XBYTES;
+    bf16x8 xf[KR], yf[CR];
+#pragma unroll
+    for (int a = 0; a < KR; ++a) xf[a] = read_tr_frag<BKK>(xs, wk * WKK + a * 16, lane);
+#pragma unroll
+    for (int b = 0; b < CR; ++b) yf[b] = read_tr_frag<BCO>(ys, wc * WCO + b * 16, lane);
+#pragma unroll
+    for (int a = 0; a < KR; ++a)
+#pragma unroll
+      for (int b = 0; b < CR; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], yf[b], acc[a][b], 0, 0, 0);
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: atomic accumulation into the HWIO fp32 gradient ------------------------------
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < KR; ++a) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kidx = k0 + wk * WKK + a * 16 + fq * 4 + r;
+      if (kidx >= p.Ktotal) continue;
+      // padded (tap, channel) -> real HWIO row
+      const uint32_t t = fd_div((uint32_t)kidx, p.divCpad);
+      const int c = kidx - (int)t * p.Cpad;
+      const uint32_t tir = fd_div(t, p.divTJpad);
+      const int tjr = (int)t - (int)tir * p.TJpad;
+      if (c >= p.Creal || tjr >= p.TJreal) continue;
+      float* row = p.dw + (size_t)(((int)tir * p.TJreal + tjr) * p.Creal + c) * p.Cout;
+#pragma unroll
+      for (int b = 0; b < CR; ++b) {
+        const int co = c0 + wc * WCO + b * 16 + fr;
+        if (co < p.Cout) atomicAdd(row + co, acc[a][b][r]);
+      }
+    }
+  }
+}
+
+template <int BKK, int BCO, int WAVES_K, int WAVES_C>
+void launch_cfg(const WgradParams& p, hipStream_t stream) {
+  const int tilesK = (p.Ktotal + BKK - 1) / BKK;
+  const int tilesC = (p.Cout + BCO - 1) / BCO;
+  const bool pointwise = p.TI == 1 && p.TJ == 1 && p.ISH == 1 && p.ISW == 1 && p.dh0 == 0 &&
+                         p.dw0 == 0 && p.OH == p.H && p.OW == p.W && p.Ctap <= p.Cpix;
+  dim3 grid(tilesK * tilesC, p.splits);
+  if (pointwise)
+    hipLaunchKernelGGL((conv_wgrad_kernel<BKK, BCO, WAVES_K, WAVES_C, true>), grid, dim3(256), 0,
+                       stream, p);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<BKK, BCO, WAVES_K, WAVES_C, false>), grid, dim3(256), 0,
+                       stream, p);
+}
+
+}  // namespace
+
+void validate_wgrad_params(const WgradParams& p) {
+  auto fail = [](const std::string& m) { throw std::invalid_argument("conv_wgrad: " + m); };
+  if (!p.x || !p.dy || !p.dw) fail("null tensor pointer");
+  if (p.P != p.N * p.OH * p.OW || p.P <= 0) fail("P != N*OH*OW");
+  if ((int64_t)p.N * p.H * p.W >= (1ll << 31) / 8) fail("input too large for 32-bit pixel index");
+  if (p.Ctap % 8 || p.Ctap <= 0) fail("Ctap must be a positive multiple of 8");
+  if (p.Ktotal != p.TI * p.TJ * p.Ctap) fail("Ktotal != TI*TJ*Ctap");
+  if (p.ldy % 8 || p.ldy < ((p.Cout + 7) / 8) * 8) fail("ldy must be a multiple of 8 covering Cout");
+  if (p.splits < 1 || p.pix_per_split % BP || (int64_t)p.splits * p.pix_per_split < p.P)
+    fail("bad split-K partition");
+  if (p.Cpad <= 0 || p.Creal <= 0 || p.Creal > p.Cpad || p.TJreal > p.TJpad) fail("bad k decode");
+  if (p.Ctap > p.Cpix) {
+    const int span = (p.Ctap + p.Cpix - 1) / p.Cpix;
+    if (p.dws < 0 || p.dhs < 0 || p.dw0 < 0 || p.dh0 < 0) fail("multi-pixel taps need forward taps");
+    if ((p.OW - 1) * p.ISW + p.dw0 + (p.TJ - 1) * p.dws + span > p.W)
+      fail("multi-pixel tap overruns the input row");
+    if ((p.OH - 1) * p.ISH + p.dh0 + (p.TI - 1) * p.dhs >= p.H) fail("multi-pixel tap overruns H");
+    if ((p.Cpix * p.ISW) % 8 || (p.Cpix * p.W) % 8) fail("multi-pixel taps need 16-byte aligned rows");
+  } else if (p.Cpix % 8) {
+    fail("Cpix must be a multiple of 8");
+  }
+}
+
+void launch_conv_wgrad(const WgradParams& p, int cfg, hipStream_t stream) {
+  validate_wgrad_params(p);
+  switch (cfg) {
+    case 0: launch_cfg<128, 128, 2, 2>(p, stream); break;
+    case 1: launch_cfg<128, 64, 2, 2>(p, stream); break;
+    case 2: launch_cfg<64, 128, 2, 2>(p, stream); break;
+    case 3: launch_cfg<64, 64, 2, 2>(p, stream); break;
+    case 4: launch_cfg<128, 32, 4, 1>(p, stream); break;
+    case 5: launch_cfg<128, 16, 4, 1>(p, stream); break;
+    case 6: launch_cfg<32, 32, 2, 2>(p, stream); break;
+    case 7: launch_cfg<64, 16, 4, 1>(p, stream); break;
+    default: throw std::invalid_argument("conv_wgrad: unknown tile config");
+  }
+}

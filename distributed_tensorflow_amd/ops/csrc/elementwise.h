@@ -1,0 +1,48 @@
+// Launchers of the bandwidth-bound kernels (BatchNorm, pooling, loss, optimizer, packing).
+#pragma once
+#include "common.h"
+
+void launch_bn_stats(const bf16_t* y, float* sum, float* sqsum, int P, int C, hipStream_t s);
+void launch_bn_apply(const bf16_t* y, const bf16_t* res, bf16_t* z, const float* sum,
+                     const float* sqsum, const float* gamma, const float* beta, float* mm,
+                     float* mv, float* save_mean, float* save_invstd, int P, int C, float eps,
+                     float momentum, int relu, int training, hipStream_t s);
+void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const float* mean,
+                   const float* invstd, const float* gamma, float* dgamma, float* dbeta,
+                   bf16_t* dy, bf16_t* dres, int P, int C, hipStream_t s);
+
+void launch_maxpool_fwd(const bf16_t* x, bf16_t* out, uint8_t* idx, int N, int H, int W, int C,
+                        int OH, int OW, int k, int stride, int pt, int pl, hipStream_t s);
+void launch_maxpool_bwd(const bf16_t* dy, const uint8_t* idx, bf16_t* dx, int N, int H, int W,
+                        int C, int OH, int OW, int k, int stride, int pt, int pl, hipStream_t s);
+void launch_global_mean_fwd(const bf16_t* x, bf16_t* out, int N, int HW, int C, hipStream_t s);
+void launch_global_mean_bwd(const bf16_t* dy, bf16_t* dx, int N, int HW, int C, hipStream_t s);
+
+// Fused softmax + cross-entropy (+ gradient) over bf16 logits with row pitch ld.
+// accum[0] += sum of per-row losses, accum[1] += number of rows whose argmax equals the label.
+void launch_softmax_xent(const bf16_t* logits, const int32_t* labels, bf16_t* dlogits,
+                         float* accum, int N, int C, int ld, float grad_scale,
+                         const float* grad_scale_dev, hipStream_t s);
+void launch_softmax_probs(const bf16_t* logits, float* probs, int N, int C, int ld, hipStream_t s);
+void launch_colsum(const bf16_t* x, float* out, int N, int C, int ld, hipStream_t s);
+
+void launch_sgd_momentum_l2(float* p, const float* g, float* v, const float* l2x2, size_t n,
+                            float lr, float momentum, float grad_scale, int use_momentum,
+                            const float* hyper, hipStream_t s);
+
+// One entry per packed bf16 weight copy (see optim.hip).
+struct PackDesc {
+  int64_t src_off;      // element offset into the flat fp32 parameter buffer (HWIO / [in,out])
+  int64_t dst_off;      // element offset into the flat bf16 packed-weight buffer
+  int32_t TI, TJ, Cin, Cout;          // real dims of the HWIO tensor
+  int32_t TJpad, Cpad, CoutPad;       // padded dims of the packed copy
+  int32_t mode;                       // 0: [Cout][TI][TJpad][Cpad]   1: [Cin][TI][TJ][CoutPad]
+  int64_t count;                      // elements of the packed copy
+  int64_t first_block;                // first thread block that works on this entry
+};
+void launch_pack_weights(const float* params, bf16_t* packed, const PackDesc* descs, int ndesc,
+                         int nblocks, hipStream_t s);
+
+void launch_preprocess_pad(const float* in, bf16_t* out, int N, int H, int W, int Cin, int pt,
+                           int pl, int OH, int OW, int Cpad, hipStream_t s);
+void launch_cast_f32_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);

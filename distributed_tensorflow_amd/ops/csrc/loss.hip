@@ -1,0 +1,128 @@
+// Fused softmax + cross-entropy forward/backward over bf16 logits (fp32 math).
+//
+// One 256-thread block per row.  The row is read once into registers (up to 16 values per
+// thread, C <= 4096), then: block max -> block sum of exp -> loss = log(sum) + max - logit[y],
+// gradient (softmax - onehot) * grad_scale written as bf16 (padding columns up to the row
+// pitch are zero-filled so that the dense-layer gradient GEMMs can read whole vectors),
+// and the first-argmax == label test for the accuracy counter.
+#include <stdexcept>
+
+#include "common.h"
+#include "elementwise.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int MAXV = 16;
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  return v;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  v = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return v;
+}
+
+template <bool PROBS>
+__global__ __launch_bounds__(TPB) void softmax_xent_kernel(
+    const bf16_t* __restrict__ logits, const int32_t* __restrict__ labels,
+    bf16_t* __restrict__ dlogits, float* __restrict__ probs, float* accum, int N, int C, int ld,
+    float grad_scale, const float* __restrict__ grad_scale_dev) {
+  if (grad_scale_dev) grad_scale = grad_scale * grad_scale_dev[0];
+  __shared__ float red[4];
+  __shared__ int redi[4];
+  const int row = blockIdx.x;
+  const bf16_t* lr = logits + (size_t)row * ld;
+  float v[MAXV];
+  float mx = -INFINITY;
+  int amax = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = threadIdx.x + i * TPB;
+    v[i] = c < C ? bf2f(lr[c]) : -INFINITY;
+    if (v[i] > mx) { mx = v[i]; amax = c; }
+  }
+  const float bmax = block_max(mx, red);
+  // first index attaining the maximum
+  int cand = (mx == bmax) ? amax : 0x7fffffff;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+  if ((threadIdx.x & 63) == 0) redi[threadIdx.x >> 6] = cand;
+  float se = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    v[i] = __expf(v[i] - bmax);   // exp(-inf) = 0 for the padding lanes
+    se += v[i];
+  }
+  const float sum = block_sum(se, red);      // contains the barrier that publishes redi
+  const int arg = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+  const float inv = 1.f / sum;
+  if (PROBS) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = threadIdx.x + i * TPB;
+      if (c < C) probs[(size_t)row * C + c] = v[i] * inv;
+    }
+    return;
+  }
+  const int label = labels[row];
+  if (dlogits) {
+    bf16_t* dr = dlogits + (size_t)row * ld;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = threadIdx.x + i * TPB;
+      if (c < ld) {
+        float g = 0.f;
+        if (c < C) g = (v[i] * inv - (c == label ? 1.f : 0.f)) * grad_scale;
+        dr[c] = f2bf(g);
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    const float ly = (label >= 0 && label < C) ? bf2f(lr[label]) : 0.f;
+    atomicAdd(accum + 0, logf(sum) + bmax - ly);
+    if (arg == label) atomicAdd(accum + 1, 1.f);
+  }
+}
+
+__global__ void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int N, int C,
+                              int ld) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += bf2f(x[(size_t)n * ld + c]);
+  atomicAdd(out + c, s);
+}
+
+}  // namespace
+
+void launch_softmax_xent(const bf16_t* logits, const int32_t* labels, bf16_t* dlogits,
+                         float* accum, int N, int C, int ld, float grad_scale,
+                         const float* grad_scale_dev, hipStream_t s) {
+  if (C > TPB * MAXV || ld > TPB * MAXV || ld < C)
+    throw std::invalid_argument("softmax_xent: at most 4096 classes, ld >= C");
+  hipLaunchKernelGGL((softmax_xent_kernel<false>), dim3(N), dim3(TPB), 0, s, logits, labels,
+                     dlogits, nullptr, accum, N, C, ld, grad_scale, grad_scale_dev);
+}
+
+void launch_softmax_probs(const bf16_t* logits, float* probs, int N, int C, int ld, hipStream_t s) {
+  if (C > TPB * MAXV || ld < C) throw std::invalid_argument("softmax_probs: at most 4096 classes");
+  hipLaunchKernelGGL((softmax_xent_kernel<true>), dim3(N), dim3(TPB), 0, s, logits, nullptr,
+                     nullptr, probs, nullptr, N, C, ld, 1.f, nullptr);
+}
+
+void launch_colsum(const bf16_t* x, float* out, int N, int C, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, s, x, out, N, C, ld);
+}

@@ -1,0 +1,167 @@
+// Optimizer, weight packing and input preprocessing kernels.
+//
+// * sgd_momentum_l2: the whole Keras SGD-momentum update over the flat fp32 buffers in one
+//   launch:  g = grad*grad_scale + l2x2*w;  v = momentum*v - lr*g;  w += v.
+//   grad_scale folds 1/replicas and 1/loss_scale; l2x2 holds 2*lambda per element (zero for
+//   BatchNorm scale/offset, which the reference does not regularise).
+// * pack_weights: one multi-tensor launch that converts every fp32 HWIO master weight into
+//   the bf16 layouts the MFMA kernels read: [Cout][taps][Cin] (K contiguous) for forward and
+//   [Cin][taps][Cout] for the data gradient, with zero padding of channels / taps where a
+//   kernel wants aligned K.
+// * preprocess_pad: fp32 NHWC images -> bf16, zero spatial padding and channel padding (the
+//   explicit ZeroPadding2D in front of the stem convolutions is materialised here, once).
+#include <stdexcept>
+
+#include "common.h"
+#include "elementwise.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f4;
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ v,
+                                                  const float* __restrict__ l2x2, size_t n4,
+                                                  size_t n, float lr, float momentum,
+                                                  float grad_scale, int use_momentum,
+                                                  const float* __restrict__ hyper) {
+  if (hyper) {   // per-step scalars live in device memory so a captured graph sees new values
+    lr = hyper[0];
+    momentum = hyper[1];
+    grad_scale = hyper[2];
+  }
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f4 w = reinterpret_cast<const f4*>(p)[i];
+    const f4 gr = reinterpret_cast<const f4*>(g)[i];
+    const f4 l2 = reinterpret_cast<const f4*>(l2x2)[i];
+    f4 gg = gr * grad_scale + l2 * w;
+    if (use_momentum) {
+      f4 vel = reinterpret_cast<const f4*>(v)[i];
+      vel = vel * momentum - gg * lr;
+      reinterpret_cast<f4*>(v)[i] = vel;
+      w += vel;
+    } else {
+      w -= gg * lr;
+    }
+    reinterpret_cast<f4*>(p)[i] = w;
+  }
+  // tail (n not a multiple of 4)
+  const size_t t = n4 * 4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t < n) {
+    float w = p[t];
+    const float gg = g[t] * grad_scale + l2x2[t] * w;
+    if (use_momentum) {
+      const float vel = v[t] * momentum - gg * lr;
+      v[t] = vel;
+      w += vel;
+    } else {
+      w -= gg * lr;
+    }
+    p[t] = w;
+  }
+}
+
+constexpr int PACK_PER_BLOCK = 256 * 8;   // packed elements handled by one block
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ params,
+                                                           bf16_t* __restrict__ packed,
+                                                           const PackDesc* __restrict__ descs,
+                                                           int ndesc) {
+  // binary search: last descriptor whose first_block <= blockIdx.x
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].first_block <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = descs[lo];
+  const int64_t base = ((int64_t)blockIdx.x - d.first_block) * PACK_PER_BLOCK;
+  const float* src = params + d.src_off;
+  bf16_t* dst = packed + d.dst_off;
+  for (int e = 0; e < 8; ++e) {
+    const int64_t i = base + e * 256 + threadIdx.x;
+    if (i >= d.count) return;
+    float val = 0.f;
+    if (d.mode == 0) {
+      // dst[co][ti][tjp][cp]
+      int64_t r = i;
+      const int cp = (int)(r % d.Cpad); r /= d.Cpad;
+      const int tjp = (int)(r % d.TJpad); r /= d.TJpad;
+      const int ti = (int)(r % d.TI);
+      const int co = (int)(r / d.TI);
+      if (cp < d.Cin && tjp < d.TJ)
+        val = src[((int64_t)(ti * d.TJ + tjp) * d.Cin + cp) * d.Cout + co];
+    } else {
+      // dst[ci][ti][tj][cop]
+      int64_t r = i;
+      const int cop = (int)(r % d.CoutPad); r /= d.CoutPad;
+      const int tj = (int)(r % d.TJ); r /= d.TJ;
+      const int ti = (int)(r % d.TI);
+      const int ci = (int)(r / d.TI);
+      if (cop < d.Cout)
+        val = src[((int64_t)(ti * d.TJ + tj) * d.Cin + ci) * d.Cout + cop];
+    }
+    dst[i] = f2bf(val);
+  }
+}
+
+__global__ __launch_bounds__(256) void preprocess_pad_kernel(const float* __restrict__ in,
+                                                             bf16_t* __restrict__ out, int N,
+                                                             int H, int W, int Cin, int pt, int pl,
+                                                             int OH, int OW, int Cpad) {
+  const size_t total = (size_t)N * OH * OW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int ow = (int)(r % OW); r /= OW;
+    const int oh = (int)(r % OH);
+    const int n = (int)(r / OH);
+    const int h = oh - pt, w = ow - pl;
+    const bool inside = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+    const float* src = in + ((size_t)(n * H + (inside ? h : 0)) * W + (inside ? w : 0)) * Cin;
+    bf16_t* dst = out + i * Cpad;
+    for (int c = 0; c < Cpad; ++c) dst[c] = f2bf((inside && c < Cin) ? src[c] : 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ in,
+                                                   bf16_t* __restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    out[i] = f2bf(in[i]);
+}
+
+inline int grid_for(size_t total) {
+  size_t b = (total + 255) / 256;
+  return (int)(b < 8192 ? (b ? b : 1) : 8192);
+}
+
+}  // namespace
+
+void launch_sgd_momentum_l2(float* p, const float* g, float* v, const float* l2x2, size_t n,
+                            float lr, float momentum, float grad_scale, int use_momentum,
+                            const float* hyper, hipStream_t s) {
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)v | (uintptr_t)l2x2) & 15)
+    throw std::invalid_argument("sgd: buffers must be 16-byte aligned");
+  const size_t n4 = n / 4;
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n4 ? n4 : 1)), dim3(256), 0, s, p, g, v, l2x2, n4, n,
+                     lr, momentum, grad_scale, use_momentum, hyper);
+}
+
+void launch_pack_weights(const float* params, bf16_t* packed, const PackDesc* descs, int ndesc,
+                         int nblocks, hipStream_t s) {
+  if (ndesc <= 0 || nblocks <= 0) return;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(nblocks), dim3(256), 0, s, params, packed, descs,
+                     ndesc);
+}
+
+void launch_preprocess_pad(const float* in, bf16_t* out, int N, int H, int W, int Cin, int pt,
+                           int pl, int OH, int OW, int Cpad, hipStream_t s) {
+  if (Cpad < Cin) throw std::invalid_argument("preprocess_pad: Cpad < Cin");
+  hipLaunchKernelGGL(preprocess_pad_kernel, dim3(grid_for((size_t)N * OH * OW)), dim3(256), 0, s,
+                     in, out, N, H, W, Cin, pt, pl, OH, OW, Cpad);
+}
+
+void launch_cast_f32_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
+}

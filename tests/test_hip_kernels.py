@@ -1,0 +1,334 @@
+"""Numerics of every hand-written HIP kernel against plain PyTorch fp32 references (GPU)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from distributed_tensorflow_amd.models.graph import same_padding
+from distributed_tensorflow_amd.ops.conv_plan import ConvGeom, round_up
+
+
+def _native():
+  from distributed_tensorflow_amd.ops import native
+  native.ext()
+  return native
+
+
+def _bf(t):
+  return t.to(torch.bfloat16)
+
+
+def _pack(native, g, w_hwio, which):
+  """Runs the pack kernel for one weight; returns the packed bf16 tensor."""
+  dev = w_hwio.device
+  d = g.pack_fwd() if which == "fwd" else g.pack_dgrad()
+  d.update(src_off=0, dst_off=0, first_block=0)
+  out = torch.zeros(round_up(d["count"], 8), dtype=torch.bfloat16, device=dev)
+  desc = torch.frombuffer(bytearray(native.pack_desc_bytes([d])), dtype=torch.uint8).to(dev)
+  native.run_op("pack_weights", dict(params=w_hwio.contiguous().data_ptr(), packed=out.data_ptr(),
+                                     descs=desc.data_ptr(), ndesc=1,
+                                     nblocks=-(-d["count"] // native.PACK_PER_BLOCK)))
+  torch.cuda.synchronize()
+  return out
+
+
+def _ref_conv(x_nhwc, w_hwio, stride, pad):
+  pt, pb, pl, pr = pad
+  x = F.pad(x_nhwc.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+  return F.conv2d(x, w_hwio.permute(3, 2, 0, 1), None, stride).permute(0, 2, 3, 1)
+
+
+CONV_CASES = [
+    # N, H, W, Cin, K, Cout, stride, padding
+    (2, 14, 14, 64, 1, 256, 1, "same"),      # 1x1 pointwise
+    (2, 14, 14, 256, 1, 64, 1, "same"),      # Cout = 64 tile
+    (3, 15, 13, 64, 3, 64, 1, "same"),       # 3x3, odd sizes (ragged M)
+    (2, 16, 16, 128, 3, 128, 2, "same"),     # 3x3 stride 2, TF pad (0,1)
+    (2, 16, 16, 256, 1, 512, 2, "same"),     # 1x1 stride 2 projection
+    (2, 8, 8, 32, 3, 32, 1, "same"),         # CIFAR-size channels
+    (2, 9, 9, 16, 3, 16, 1, "same"),         # Cout = 16 tile
+    (2, 8, 8, 16, 3, 32, 2, "same"),
+    (4, 7, 7, 512, 3, 512, 1, "same"),       # deep K = 4608
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case):
+  native = _native()
+  N, H, W, Cin, K, Cout, stride, padding = case
+  dev = torch.device("cuda")
+  gen = torch.Generator(device="cpu").manual_seed(hash(case) & 0xffff)
+  pad = same_padding(H, K, stride) + same_padding(W, K, stride)
+  g = ConvGeom(N, H, W, Cin, K, K, Cout, stride, pad)
+  x = _bf(torch.randn(N, H, W, Cin, generator=gen)).to(dev)
+  w = (torch.randn(K, K, Cin, Cout, generator=gen) * (1.0 / math.sqrt(K * K * Cin))).to(dev)
+  wq = _bf(w).float()
+  # ---- forward
+  wf = _pack(native, g, w, "fwd")
+  out = torch.full(g.output_shape, float("nan"), dtype=torch.bfloat16, device=dev)
+  native.run_op("conv", g.fwd(x.data_ptr(), wf.data_ptr(), out.data_ptr()))
+  torch.cuda.synchronize()
+  ref = _ref_conv(x.float(), wq, stride, pad)
+  assert out.shape[:3] == ref.shape[:3]
+  err = (out.float() - ref).abs().max().item()
+  assert err <= 0.02 * ref.abs().max().item() + 1e-2, err
+  # ---- data gradient (fp32 autograd reference on the same bf16-rounded operands)
+  dy = _bf(torch.randn(N, g.OH, g.OW, Cout, generator=gen)).to(dev)
+  xr = x.float().requires_grad_(True)
+  wr = wq.clone().requires_grad_(True)
+  _ref_conv(xr, wr, stride, pad).backward(dy.float())
+  wd = _pack(native, g, w, "dgrad")
+  dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=dev)
+  for d in g.dgrad(dy.data_ptr(), wd.data_ptr(), dx.data_ptr()):
+    native.run_op("conv", d)
+  torch.cuda.synchronize()
+  err = (dx.float() - xr.grad).abs().max().item()
+  assert err <= 0.02 * xr.grad.abs().max().item() + 1e-2, err
+  # accumulate mode adds to the existing tensor
+  dx2 = dx.clone()
+  for d in g.dgrad(dy.data_ptr(), wd.data_ptr(), dx2.data_ptr(), accumulate=True):
+    native.run_op("conv", d)
+  torch.cuda.synchronize()
+  assert torch.allclose(dx2.float(), 2 * dx.float(), rtol=2e-2, atol=2e-2)
+  # ---- weight gradient (fp32 atomics into HWIO)
+  dw = torch.zeros(K, K, Cin, Cout, dtype=torch.float32, device=dev)
+  native.run_op("wgrad", g.wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr()))
+  torch.cuda.synchronize()
+  err = (dw - wr.grad).abs().max().item()
+  assert err <= 0.01 * wr.grad.abs().max().item() + 1e-2, err
+
+
+def test_conv_mfma_layout_identity():
+  """A = I with an asymmetric B: catches a transposed / permuted accumulator mapping."""
+  native = _native()
+  dev = torch.device("cuda")
+  C = 128
+  g = ConvGeom(1, 16, 16, C, 1, 1, C)
+  x = torch.zeros(1, 16, 16, C, dtype=torch.bfloat16, device=dev)
+  idx = torch.arange(256, device=dev)
+  x.view(256, C)[idx, idx % C] = 1.0                     # pixel p selects channel p % C
+  w = (torch.arange(C * C, device=dev, dtype=torch.float32).reshape(1, 1, C, C) % 251) - 125
+  wf = _pack(native, g, w, "fwd")
+  out = torch.zeros(g.output_shape, dtype=torch.bfloat16, device=dev)
+  native.run_op("conv", g.fwd(x.data_ptr(), wf.data_ptr(), out.data_ptr()))
+  torch.cuda.synchronize()
+  ref = w[0, 0][idx % C]                                 # row (p % C) of W for pixel p
+  assert torch.equal(out.view(256, C).float(), _bf(ref).float())
+
+
+def test_stem_merged_taps_and_dense():
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator().manual_seed(3)
+  # ImageNet stem: 7x7/2, explicit pad 3, 3 channels (merged-tap mode)
+  N, H = 2, 32
+  g = ConvGeom(N, H, H, 3, 7, 7, 64, 2, (3, 3, 3, 3), mode="merged")
+  img = torch.randn(N, H, H, 3, generator=gen).to(dev) * 50 + 100
+  xin = torch.zeros(g.input_shape, dtype=torch.bfloat16, device=dev)
+  native.run_op("preprocess_pad", dict(N=N, H=H, W=H, Cin=3, pt=3, pl=3, OH=g.Hs, OW=g.Ws, Cpad=4,
+                                       out=xin.data_ptr(), **{"in": img.data_ptr()}))
+  w = (torch.randn(7, 7, 3, 64, generator=gen) * 0.05).to(dev)
+  wf = _pack(native, g, w, "fwd")
+  out = torch.zeros(g.output_shape, dtype=torch.bfloat16, device=dev)
+  native.run_op("conv", g.fwd(xin.data_ptr(), wf.data_ptr(), out.data_ptr()))
+  torch.cuda.synchronize()
+  ref = _ref_conv(_bf(img).float(), _bf(w).float(), 2, (3, 3, 3, 3))
+  assert (out.float() - ref).abs().max().item() <= 0.02 * ref.abs().max().item()
+  dy = _bf(torch.randn(N, g.OH, g.OW, 64, generator=gen)).to(dev)
+  dw = torch.zeros(7, 7, 3, 64, device=dev)
+  native.run_op("wgrad", g.wgrad(xin.data_ptr(), dy.data_ptr(), dw.data_ptr()))
+  torch.cuda.synchronize()
+  wr = _bf(w).float().requires_grad_(True)
+  _ref_conv(_bf(img).float(), wr, 2, (3, 3, 3, 3)).backward(dy.float())
+  assert (dw - wr.grad).abs().max().item() <= 0.01 * wr.grad.abs().max().item() + 1e-2
+  # dense layer 256 -> 1001 (ragged N, bias, pitch 1008)
+  B, fin, fout = 16, 256, 1001
+  gd = ConvGeom(B, 1, 1, fin, 1, 1, fout)
+  xd = _bf(torch.randn(B, fin, generator=gen)).to(dev)
+  wd_ = (torch.randn(1, 1, fin, fout, generator=gen) * 0.05).to(dev)
+  bias = torch.randn(fout, generator=gen).to(dev)
+  wfd = _pack(native, gd, wd_, "fwd")
+  logits = torch.zeros(B, gd.ldc, dtype=torch.bfloat16, device=dev)
+  native.run_op("conv", gd.fwd(xd.data_ptr(), wfd.data_ptr(), logits.data_ptr(), bias=bias.data_ptr()))
+  torch.cuda.synchronize()
+  ref = xd.float() @ _bf(wd_[0, 0]).float() + bias
+  assert gd.ldc == 1008
+  assert (logits[:, :fout].float() - ref).abs().max().item() <= 0.03 * ref.abs().max().item()
+  assert torch.all(logits[:, fout:] == 0)
+  dl = torch.zeros(B, gd.ldc, dtype=torch.bfloat16, device=dev)
+  dl[:, :fout] = _bf(torch.randn(B, fout, generator=gen)).to(dev)
+  wdd = _pack(native, gd, wd_, "dgrad")
+  dxd = torch.zeros(B, fin, dtype=torch.bfloat16, device=dev)
+  for d in gd.dgrad(dl.data_ptr(), wdd.data_ptr(), dxd.data_ptr()):
+    native.run_op("conv", d)
+  dwd = torch.zeros(fin, fout, device=dev)
+  native.run_op("wgrad", gd.wgrad(xd.data_ptr(), dl.data_ptr(), dwd.data_ptr()))
+  torch.cuda.synchronize()
+  ref_dx = dl[:, :fout].float() @ _bf(wd_[0, 0]).float().t()
+  ref_dw = xd.float().t() @ dl[:, :fout].float()
+  assert (dxd.float() - ref_dx).abs().max().item() <= 0.03 * ref_dx.abs().max().item()
+  assert (dwd - ref_dw).abs().max().item() <= 0.01 * ref_dw.abs().max().item() + 1e-2
+
+
+@pytest.mark.parametrize("C,relu,residual", [(64, True, False), (256, True, True),
+                                             (16, False, False), (2048, True, True)])
+def test_batchnorm_fwd_bwd(C, relu, residual):
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator().manual_seed(C)
+  P = 8 * 7 * 7
+  y = _bf(torch.randn(P, C, generator=gen) * 2 + 0.5).to(dev)
+  res = _bf(torch.randn(P, C, generator=gen)).to(dev) if residual else None
+  gamma = (torch.rand(C, generator=gen) + 0.5).to(dev)
+  beta = (torch.randn(C, generator=gen) * 0.1).to(dev)
+  mm = torch.zeros(C, device=dev)
+  mv = torch.ones(C, device=dev)
+  stats = torch.zeros(2 * C, device=dev)
+  saved = torch.zeros(2 * C, device=dev)
+  z = torch.empty(P, C, dtype=torch.bfloat16, device=dev)
+  native.run_op("bn_stats", dict(y=y.data_ptr(), sum=stats.data_ptr(), sqsum=stats.data_ptr() + 4 * C, P=P, C=C))
+  native.run_op("bn_apply", dict(y=y.data_ptr(), res=res.data_ptr() if residual else None, z=z.data_ptr(),
+                                 sum=stats.data_ptr(), sqsum=stats.data_ptr() + 4 * C, gamma=gamma.data_ptr(),
+                                 beta=beta.data_ptr(), mm=mm.data_ptr(), mv=mv.data_ptr(),
+                                 save_mean=saved.data_ptr(), save_invstd=saved.data_ptr() + 4 * C,
+                                 P=P, C=C, eps=1e-5, momentum=0.9, relu=int(relu), training=1))
+  torch.cuda.synchronize()
+  yr = y.float().requires_grad_(True)
+  gr = gamma.clone().requires_grad_(True)
+  br = beta.clone().requires_grad_(True)
+  rr = res.float().requires_grad_(True) if residual else None
+  mean = yr.mean(0)
+  var = yr.var(0, unbiased=False)
+  zr = (yr - mean) * torch.rsqrt(var + 1e-5) * gr + br
+  if residual:
+    zr = zr + rr
+  if relu:
+    zr = torch.relu(zr)
+  assert torch.allclose(z.float(), zr.detach(), rtol=2e-2, atol=2e-2)
+  assert torch.allclose(mm, 0.1 * mean.detach(), rtol=1e-3, atol=1e-4)
+  assert torch.allclose(mv, 0.9 + 0.1 * yr.detach().var(0, unbiased=True), rtol=1e-3, atol=1e-4)
+  # backward
+  dz = _bf(torch.randn(P, C, generator=gen)).to(dev)
+  # reference mask must come from the bf16 output the kernel saved
+  zq = z.float()
+  g = dz.float() * (zq > 0) if relu else dz.float()
+  xhat = ((yr - mean) * torch.rsqrt(var + 1e-5)).detach()
+  dgamma_ref = (g * xhat).sum(0)
+  dbeta_ref = g.sum(0)
+  dy_ref = gamma * torch.rsqrt(var.detach() + 1e-5) * (g - dbeta_ref / P - xhat * dgamma_ref / P)
+  dgamma = torch.zeros(C, device=dev)
+  dbeta = torch.zeros(C, device=dev)
+  dy = torch.empty(P, C, dtype=torch.bfloat16, device=dev)
+  dres = torch.empty(P, C, dtype=torch.bfloat16, device=dev) if residual else None
+  native.run_op("bn_bwd", dict(dz=dz.data_ptr(), y=y.data_ptr(), z=z.data_ptr() if relu else None,
+                               mean=saved.data_ptr(), invstd=saved.data_ptr() + 4 * C, gamma=gamma.data_ptr(),
+                               dgamma=dgamma.data_ptr(), dbeta=dbeta.data_ptr(), dy=dy.data_ptr(),
+                               dres=dres.data_ptr() if residual else None, P=P, C=C))
+  torch.cuda.synchronize()
+  assert torch.allclose(dgamma, dgamma_ref, rtol=1e-2, atol=5e-2)
+  assert torch.allclose(dbeta, dbeta_ref, rtol=1e-2, atol=5e-2)
+  assert torch.allclose(dy.float(), dy_ref, rtol=3e-2, atol=3e-2)
+  if residual:
+    assert torch.equal(dres.float(), _bf(g).float())
+  # inference mode uses the moving statistics
+  z2 = torch.empty_like(z)
+  native.run_op("bn_apply", dict(y=y.data_ptr(), res=None, z=z2.data_ptr(), sum=None, sqsum=None,
+                                 gamma=gamma.data_ptr(), beta=beta.data_ptr(), mm=mm.data_ptr(), mv=mv.data_ptr(),
+                                 save_mean=None, save_invstd=None, P=P, C=C, eps=1e-5, momentum=0.9,
+                                 relu=0, training=0))
+  torch.cuda.synchronize()
+  ref2 = (y.float() - mm) * torch.rsqrt(mv + 1e-5) * gamma + beta
+  assert torch.allclose(z2.float(), ref2, rtol=2e-2, atol=2e-2)
+
+
+def test_pooling():
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator().manual_seed(5)
+  N, H, W, C = 2, 12, 12, 64
+  x = torch.relu(_bf(torch.randn(N, H, W, C, generator=gen))).to(dev)     # zeros -> ties
+  OH = OW = 6
+  out = torch.empty(N, OH, OW, C, dtype=torch.bfloat16, device=dev)
+  idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device=dev)
+  args = dict(N=N, H=H, W=W, C=C, OH=OH, OW=OW, k=3, stride=2, pt=0, pl=0, idx=idx.data_ptr())
+  native.run_op("maxpool_fwd", dict(x=x.data_ptr(), out=out.data_ptr(), **args))
+  xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+  ref = F.max_pool2d(F.pad(xr, (0, 1, 0, 1), value=float("-inf")), 3, 2)
+  torch.cuda.synchronize()
+  assert torch.equal(out.float(), ref.detach().permute(0, 2, 3, 1))
+  dy = _bf(torch.randn(N, OH, OW, C, generator=gen)).to(dev)
+  dx = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=dev)
+  native.run_op("maxpool_bwd", dict(dy=dy.data_ptr(), dx=dx.data_ptr(), **args))
+  torch.cuda.synchronize()
+  # gradient mass is conserved and lands on maxima
+  assert torch.allclose(dx.float().sum((1, 2)), dy.float().sum((1, 2)), rtol=1e-2, atol=0.3)
+  ref.backward(dy.float().permute(0, 3, 1, 2))
+  nz = x.float() > 0          # away from the ReLU ties both implementations must agree
+  assert torch.allclose(dx.float()[nz], xr.grad.permute(0, 2, 3, 1)[nz], rtol=2e-2, atol=2e-2)
+  # global mean
+  m = torch.empty(N, C, dtype=torch.bfloat16, device=dev)
+  native.run_op("mean_fwd", dict(x=x.data_ptr(), out=m.data_ptr(), N=N, HW=H * W, C=C))
+  torch.cuda.synchronize()
+  assert torch.allclose(m.float(), x.float().mean((1, 2)), rtol=1e-2, atol=1e-2)
+  dm = _bf(torch.randn(N, C, generator=gen)).to(dev)
+  dxx = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=dev)
+  native.run_op("mean_bwd", dict(dy=dm.data_ptr(), dx=dxx.data_ptr(), N=N, HW=H * W, C=C))
+  torch.cuda.synchronize()
+  assert torch.allclose(dxx.float(), (dm.float() / (H * W))[:, None, None, :].expand(N, H, W, C),
+                        rtol=1e-2, atol=1e-4)
+
+
+@pytest.mark.parametrize("C,ld", [(1001, 1008), (10, 16)])
+def test_softmax_xent(C, ld):
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator().manual_seed(7)
+  N = 32
+  logits = torch.zeros(N, ld, dtype=torch.bfloat16, device=dev)
+  logits[:, :C] = _bf(torch.randn(N, C, generator=gen) * 3).to(dev)
+  labels = torch.randint(0, C, (N,), generator=gen).to(dev)
+  labels[:4] = logits[:4, :C].float().argmax(1)          # some correct predictions
+  lab32 = labels.to(torch.int32)
+  dl = torch.full((N, ld), float("nan"), dtype=torch.bfloat16, device=dev)
+  acc = torch.zeros(2, device=dev)
+  scale = torch.full((1,), 128.0, device=dev)
+  native.run_op("softmax_xent", dict(logits=logits.data_ptr(), labels=lab32.data_ptr(), dlogits=dl.data_ptr(),
+                                     accum=acc.data_ptr(), N=N, C=C, ld=ld, grad_scale=1.0 / N,
+                                     grad_scale_dev=scale.data_ptr()))
+  torch.cuda.synchronize()
+  lr = logits[:, :C].float().requires_grad_(True)
+  loss = F.cross_entropy(lr, labels, reduction="sum")
+  (loss * 128.0 / N).backward()
+  assert acc[0].item() == pytest.approx(loss.item(), rel=1e-4)
+  assert acc[1].item() == (lr.argmax(1) == labels).sum().item()
+  assert torch.allclose(dl[:, :C].float(), lr.grad, rtol=2e-2, atol=2e-3)
+  assert torch.all(dl[:, C:] == 0)
+  probs = torch.empty(N, C, device=dev)
+  native.run_op("softmax_probs", dict(logits=logits.data_ptr(), probs=probs.data_ptr(), N=N, C=C, ld=ld))
+  torch.cuda.synchronize()
+  assert torch.allclose(probs, torch.softmax(lr.detach(), 1), rtol=1e-4, atol=1e-6)
+  cs = torch.zeros(C, device=dev)
+  native.run_op("colsum", dict(x=dl.data_ptr(), out=cs.data_ptr(), N=N, C=C, ld=ld))
+  torch.cuda.synchronize()
+  assert torch.allclose(cs, dl[:, :C].float().sum(0), rtol=1e-4, atol=1e-4)
+
+
+def test_fused_sgd_matches_keras_rule():
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator().manual_seed(11)
+  n = 100003 * 4
+  p = torch.randn(n, generator=gen).to(dev)
+  g = torch.randn(n, generator=gen).to(dev)
+  v = torch.randn(n, generator=gen).to(dev) * 0.1
+  l2 = torch.where(torch.rand(n, generator=gen) < 0.5, 2e-4, 0.0).to(dev)
+  p0, v0 = p.clone(), v.clone()
+  native.sgd_momentum_l2(p, g, v, l2, lr=0.1, momentum=0.9, grad_scale=0.125)
+  torch.cuda.synchronize()
+  gg = g * 0.125 + l2 * p0
+  v_ref = 0.9 * v0 - 0.1 * gg
+  assert torch.allclose(v, v_ref, rtol=1e-6, atol=1e-7)
+  assert torch.allclose(p, p0 + v_ref, rtol=1e-6, atol=1e-7)
