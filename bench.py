@@ -1,0 +1,155 @@
+"""Headline benchmark: ResNet-50 v1.5 / ImageNet-224 training throughput on N MI355X.
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29511 bench.py --gpus 8 --steps 30 --warmup 5
+
+Config (the one BASELINE.json names): ResNet-50 v1.5, 1001 classes, 224x224x3, batch 256
+per GPU, bf16 compute with fp32 master weights, synthetic data resident on the device,
+random-init weights, SGD-momentum + L2 (the full optimizer step is inside the timed region).
+N > 1 is synchronous data parallelism, one process per GPU, fused-bucket RCCL all-reduce
+overlapped with the backward pass; weak scaling (per-GPU batch fixed).
+
+Rank 0 prints ONE JSON line. `value` is whole-job images/second (global batch * steps /
+max-over-ranks wall time).  `vs_baseline` divides by the reference's published Horovod
+throughput at the nearest published GPU count >= N (1 GPU: 175.5 img/s, 4: 597.8, 16: 1428.3,
+Tesla P40, fp32).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+REFERENCE_IMG_PER_SEC = {1: 175.5, 4: 597.8, 16: 1428.3}   # reference README.md:258-264
+
+
+def baseline_for(n: int) -> float:
+  for k in sorted(REFERENCE_IMG_PER_SEC):
+    if n <= k:
+      return REFERENCE_IMG_PER_SEC[k]
+  return REFERENCE_IMG_PER_SEC[16]
+
+
+def main() -> int:
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=30)
+  ap.add_argument("--warmup", type=int, default=5)
+  ap.add_argument("--batch", type=int, default=256, help="per-GPU batch size")
+  ap.add_argument("--model", default="resnet50", choices=["resnet50", "resnet56"])
+  ap.add_argument("--num_packs", type=int, default=4, help="gradient fusion buckets")
+  ap.add_argument("--all_reduce_alg", default=None)
+  ap.add_argument("--no_graph", action="store_true")
+  ap.add_argument("--executor", default="hip", choices=["hip", "torch"])
+  a = ap.parse_args()
+
+  from distributed_tensorflow_amd import models
+  from distributed_tensorflow_amd.data.synthetic import SyntheticDataset
+  from distributed_tensorflow_amd.parallel import strategy as strategy_lib
+  from distributed_tensorflow_amd.train.model import Model
+  from distributed_tensorflow_amd.train.optimizers import SGD
+  from distributed_tensorflow_amd.utils import logging
+
+  logging.set_verbosity(logging.WARNING)
+  if a.no_graph:
+    os.environ["DTF_HIP_GRAPH"] = "0"
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  if world != a.gpus:
+    if world == 1 and a.gpus > 1:
+      sys.stderr.write("bench.py: --gpus %d needs a launcher (torch.distributed.run "
+                       "--nproc-per-node %d)\n" % (a.gpus, a.gpus))
+      return 2
+    a.gpus = world
+  if not torch.cuda.is_available():
+    sys.stderr.write("bench.py needs a GPU\n")
+    return 2
+
+  if a.gpus > 1:
+    strat = strategy_lib.MirroredStrategy(use_gpu=True, all_reduce_alg=a.all_reduce_alg,
+                                          num_packs=a.num_packs)
+    device = strat.device
+    rank = strat.rank
+  else:
+    strat = None
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(device)
+    rank = 0
+
+  if a.model == "resnet50":
+    spec, shape, classes = models.resnet50(), (224, 224, 3), 1001
+    loss, metric = "sparse_categorical_crossentropy", "sparse_categorical_accuracy"
+  else:
+    spec, shape, classes = models.resnet56(), (32, 32, 3), 10
+    loss, metric = "sparse_categorical_crossentropy", "sparse_categorical_accuracy"
+
+  model = Model(spec, strategy=strat, dtype="bf16", device=device, executor=a.executor)
+  from distributed_tensorflow_amd.train import schedules
+  global_batch = a.batch * a.gpus
+  if a.model == "resnet50":
+    steps_per_epoch = 1281167 / global_batch
+    lr_at = lambda i: schedules.imagenet_learning_rate_schedule(0, i, steps_per_epoch, global_batch)
+  else:
+    lr_at = lambda i: schedules.cifar_learning_rate_schedule(0, i, 50000 / global_batch, global_batch)
+  opt = SGD(lr_at(0), momentum=0.9)
+  model.compile(opt, loss, [metric])
+  # one random image and label per sample, resident on the device (no input pipeline)
+  ds = SyntheticDataset(shape[0], shape[1], shape[2], classes, a.batch, device,
+                        seed=int(os.environ.get("RANK", "0")), per_sample_random=True)
+  images, labels = next(iter(ds))
+  model._sync_initial_variables()  # pylint: disable=protected-access
+
+  def sync():
+    if strat is not None:
+      strat.barrier()
+    torch.cuda.synchronize(device)
+
+  last = None
+  for i in range(a.warmup):
+    opt.learning_rate = lr_at(i)          # the reference's per-batch schedule (warm-up phase)
+    last = model.train_on_batch(images, labels)
+  sync()
+  t0 = time.perf_counter()
+  for i in range(a.steps):
+    opt.learning_rate = lr_at(a.warmup + i)
+    last = model.train_on_batch(images, labels)
+  sync()
+  dt = time.perf_counter() - t0
+  if strat is not None:
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+  loss_val = float(last[0].item())
+  if rank == 0:
+    value = global_batch * a.steps / dt
+    out = {
+        "metric": "images/sec (whole node) ResNet-50 ImageNet-224 bs256/GPU",
+        "value": round(value, 2), "unit": "images/sec", "n_gpus": a.gpus, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(1000.0 * dt / a.steps, 3),
+        "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": round(value / baseline_for(a.gpus), 3), "dtype": "bf16",
+        "data": "synthetic (device-resident batch), random-init weights",
+        "config": {"model": "resnet50_v1.5" if a.model == "resnet50" else a.model,
+                   "global_batch": global_batch, "per_gpu_batch": a.batch,
+                   "image": "%dx%dx%d" % shape, "classes": classes,
+                   "optimizer": "sgd_momentum_l2", "parallelism": "dp%d" % a.gpus,
+                   "executor": model.executor_kind, "final_loss": round(loss_val, 4),
+                   "baseline_img_per_sec": baseline_for(a.gpus)}}
+    print(json.dumps(out), flush=True)
+  if strat is not None:
+    strat.barrier()
+    from distributed_tensorflow_amd.parallel import comm
+    comm.shutdown()
+  return 0
+
+
+if __name__ == "__main__":
+  sys.exit(main())

@@ -156,13 +156,14 @@ class HipExecutor:
     # ---- BatchNorm side buffers -------------------------------------------------------------
     bn_ops = [o for o in spec.ops if o.kind == "bn"]
     tot = sum(o.attrs["channels"] for o in bn_ops)
-    self.bn_stats = self._alloc((2 * max(tot, 1),), torch.float32)    # [sum | sqsum] per layer
-    self.bn_saved = self._alloc((2 * max(tot, 1),), torch.float32)    # [mean | invstd] per layer
+    # per layer: [mean | invstd | scale | shift]; one workspace of per-block partial sums
+    self.bn_saved = self._alloc((4 * max(tot, 1),), torch.float32)
+    self.bn_ws = self._alloc((native.ext().bn_workspace_floats(),), torch.float32)
     bn_off: Dict[str, int] = {}
     o = 0
     for b in bn_ops:
       bn_off[b.name] = o
-      o += 2 * b.attrs["channels"]
+      o += 4 * b.attrs["channels"]
     self._bn_off = bn_off
 
     ext = native.ext()
@@ -224,9 +225,6 @@ class HipExecutor:
   def _build_forward(self, plan, training: bool):
     spec, N = self.spec, self.N
     acts = self.acts
-    if training:
-      plan.add("memset", dict(ptr=self.bn_stats.data_ptr(), nbytes=self.bn_stats.numel() * 4),
-               "zero_bn_stats")
     plan.add("memset", dict(ptr=self.accum.data_ptr(), nbytes=8), "zero_loss")
     plan.add("preprocess_pad", self._pre, "preprocess")
     for op in spec.ops:
@@ -244,21 +242,21 @@ class HipExecutor:
         C = at["channels"]
         P = x.numel() // C
         so = self._bn_off[op.name]
-        sum_p = self.bn_stats.data_ptr() + 4 * so
-        sq_p = sum_p + 4 * C
         mean_p = self.bn_saved.data_ptr() + 4 * so
-        inv_p = mean_p + 4 * C
-        if training:
-          plan.add("bn_stats", dict(y=x.data_ptr(), sum=sum_p, sqsum=sq_p, P=P, C=C),
-                   op.name + "/stats")
         res = acts[op.inputs[1]].data_ptr() if len(op.inputs) > 1 else None
-        plan.add("bn_apply", dict(
-            y=x.data_ptr(), res=res, z=acts[op.output].data_ptr(), sum=sum_p, sqsum=sq_p,
-            gamma=self._var_ptr(op.name + "/gamma"), beta=self._var_ptr(op.name + "/beta"),
-            mm=self._var_ptr(op.name + "/moving_mean"),
-            mv=self._var_ptr(op.name + "/moving_variance"), save_mean=mean_p, save_invstd=inv_p,
-            P=P, C=C, eps=float(at["eps"]), momentum=float(at["momentum"]),
-            relu=int(at["relu"]), training=int(training)), op.name)
+        common = dict(y=x.data_ptr(), res=res, z=acts[op.output].data_ptr(),
+                      gamma=self._var_ptr(op.name + "/gamma"),
+                      beta=self._var_ptr(op.name + "/beta"),
+                      mm=self._var_ptr(op.name + "/moving_mean"),
+                      mv=self._var_ptr(op.name + "/moving_variance"),
+                      P=P, C=C, eps=float(at["eps"]), relu=int(at["relu"]))
+        if training:
+          plan.add("bn_fwd_train", dict(
+              save_mean=mean_p, save_invstd=mean_p + 4 * C, scale=mean_p + 8 * C,
+              shift=mean_p + 12 * C, ws=self.bn_ws.data_ptr(), momentum=float(at["momentum"]),
+              **common), op.name)
+        else:
+          plan.add("bn_infer", common, op.name)
       elif op.kind == "maxpool":
         h, w, c = spec.shapes[op.inputs[0]]
         ho, wo, _ = spec.shapes[op.output]
@@ -380,7 +378,7 @@ class HipExecutor:
             gamma=self._var_ptr(op.name + "/gamma"),
             dgamma=self._var_ptr(op.name + "/gamma", "grad"),
             dbeta=self._var_ptr(op.name + "/beta", "grad"), dy=dy.data_ptr(), dres=dres,
-            P=P, C=C), op.name + "/bwd")
+            ws=self.bn_ws.data_ptr(), P=P, C=C), op.name + "/bwd")
         written.add(xname)
         done([op.name + "/gamma", op.name + "/beta"])
       elif op.kind == "conv":

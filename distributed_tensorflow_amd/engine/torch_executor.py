@@ -46,6 +46,8 @@ class TorchExecutor:
     self.dtype = TORCH_DTYPES[dtype]
     self.device = store.device
     self.buckets = buckets if buckets is not None else store.make_buckets(1)
+    self.debug_keep_activations = False     # tests: keep (and retain the grads of) activations
+    self.last_activations: Dict[str, torch.Tensor] = {}
     self._leaves: Dict[str, torch.Tensor] = {}
     for e in store.trainable:
       p = store.view(e.spec.name)           # view of the flat buffer, not requiring grad
@@ -101,7 +103,11 @@ class TorchExecutor:
         out = torch.addmm(b, src, w)
       else:
         raise NotImplementedError(op.kind)
+      if self.debug_keep_activations and training and out.requires_grad:
+        out.retain_grad()
       t[op.output] = out
+    if self.debug_keep_activations:
+      self.last_activations = t
     return t[self.spec.logits_name].float()
 
   # -- public API ------------------------------------------------------------------

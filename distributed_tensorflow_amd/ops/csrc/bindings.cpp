@@ -120,28 +120,31 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     const int cfg = get_or<int>(d, "cfg", 0);
     return [p, cfg](hipStream_t s) { launch_conv_wgrad(p, cfg, s); };
   }
-  if (kind == "bn_stats") {
-    auto y = ptr<const bf16_t>(d, "y"); auto sum = ptr<float>(d, "sum");
-    auto sq = ptr<float>(d, "sqsum");
-    const int P = get<int>(d, "P"), C = get<int>(d, "C");
-    return [=](hipStream_t s) { launch_bn_stats(y, sum, sq, P, C, s); };
-  }
-  if (kind == "bn_apply") {
+  if (kind == "bn_fwd_train") {
     auto y = ptr<const bf16_t>(d, "y"); auto res = ptr<const bf16_t>(d, "res", false);
     auto z = ptr<bf16_t>(d, "z");
-    auto sum = ptr<const float>(d, "sum", false); auto sq = ptr<const float>(d, "sqsum", false);
     auto gamma = ptr<const float>(d, "gamma"); auto beta = ptr<const float>(d, "beta");
     auto mm = ptr<float>(d, "mm"); auto mv = ptr<float>(d, "mv");
-    auto smean = ptr<float>(d, "save_mean", false); auto sinv = ptr<float>(d, "save_invstd", false);
+    auto smean = ptr<float>(d, "save_mean"); auto sinv = ptr<float>(d, "save_invstd");
+    auto scale = ptr<float>(d, "scale"); auto shift = ptr<float>(d, "shift");
+    auto ws = ptr<float>(d, "ws");
     const int P = get<int>(d, "P"), C = get<int>(d, "C");
     const float eps = get<float>(d, "eps"), mom = get<float>(d, "momentum");
-    const int relu = get<int>(d, "relu"), training = get<int>(d, "training");
-    if (training && (!sum || !sq || !smean || !sinv))
-      throw std::invalid_argument("bn_apply: training needs sum/sqsum/save_mean/save_invstd");
+    const int relu = get<int>(d, "relu");
     return [=](hipStream_t s) {
-      launch_bn_apply(y, res, z, sum, sq, gamma, beta, mm, mv, smean, sinv, P, C, eps, mom, relu,
-                      training, s);
+      launch_bn_fwd_train(y, res, z, gamma, beta, mm, mv, smean, sinv, scale, shift, ws, P, C,
+                          eps, mom, relu, s);
     };
+  }
+  if (kind == "bn_infer") {
+    auto y = ptr<const bf16_t>(d, "y"); auto res = ptr<const bf16_t>(d, "res", false);
+    auto z = ptr<bf16_t>(d, "z");
+    auto gamma = ptr<const float>(d, "gamma"); auto beta = ptr<const float>(d, "beta");
+    auto mm = ptr<const float>(d, "mm"); auto mv = ptr<const float>(d, "mv");
+    const int P = get<int>(d, "P"), C = get<int>(d, "C");
+    const float eps = get<float>(d, "eps");
+    const int relu = get<int>(d, "relu");
+    return [=](hipStream_t s) { launch_bn_infer(y, res, z, gamma, beta, mm, mv, P, C, eps, relu, s); };
   }
   if (kind == "bn_bwd") {
     auto dz = ptr<const bf16_t>(d, "dz"); auto y = ptr<const bf16_t>(d, "y");
@@ -150,9 +153,10 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     auto gamma = ptr<const float>(d, "gamma");
     auto dgamma = ptr<float>(d, "dgamma"); auto dbeta = ptr<float>(d, "dbeta");
     auto dy = ptr<bf16_t>(d, "dy"); auto dres = ptr<bf16_t>(d, "dres", false);
+    auto ws = ptr<float>(d, "ws");
     const int P = get<int>(d, "P"), C = get<int>(d, "C");
     return [=](hipStream_t s) {
-      launch_bn_bwd(dz, y, z, mean, inv, gamma, dgamma, dbeta, dy, dres, P, C, s);
+      launch_bn_bwd(dz, y, z, mean, inv, gamma, dgamma, dbeta, dy, dres, ws, P, C, s);
     };
   }
   if (kind == "maxpool_fwd" || kind == "maxpool_bwd") {
@@ -299,6 +303,7 @@ PYBIND11_MODULE(_dtf_native, m) {
   }, py::arg("kind"), py::arg("args"), py::arg("stream") = 0);
   m.def("fastdiv_check", [](uint32_t n, uint32_t d) { return fd_div(n, make_fastdiv(d)); });
   m.def("pack_desc_size", []() { return (int)sizeof(PackDesc); });
+  m.def("bn_workspace_floats", []() { return bn_workspace_floats(); });
   m.attr("PACK_PER_BLOCK") = 256 * 8;
   m.attr("arch") = "gfx950";
   py::class_<Plan>(m, "Plan")

@@ -2,16 +2,20 @@
 //
 // Training forward is   z = relu?( gamma * (y - mean) * invstd + beta (+ residual) )
 // with per-channel batch statistics over all P = N*H*W pixels, computed in fp32 from the
-// bf16 convolution output.  The statistics pass (`bn_stats`) produces sum and sum of squares;
-// `bn_apply` derives scale/shift in its prologue (so there is no separate "finalize" launch),
-// applies normalisation + residual add + ReLU in one sweep, stores mean / invstd for the
-// backward pass and lets block 0 update the moving averages with the Keras/TensorFlow rule
-//   moving = moving * m + batch * (1 - m),   batch variance *unbiased* for the moving average.
+// bf16 convolution output.  Three launches: `bn_stats` sweeps the tensor once and leaves one
+// row of partial sums per block in a workspace (plain stores - same-address atomics from a
+// thousand blocks serialise in L2 and were 10x slower than the sweep itself);
+// `bn_fwd_finalize` (one block per 32 channels) reduces the partials, derives scale / shift,
+// stores mean / invstd for backward and updates the moving averages with the Keras/TensorFlow
+// rule  moving = moving * m + batch * (1 - m)  (batch variance *unbiased* for the moving
+// average); `bn_apply` does normalisation + residual add + ReLU in one sweep.
 //
-// Backward is two sweeps: `bn_bwd_reduce` (ReLU mask from the saved output, dgamma / dbeta
-// reductions straight into the flat fp32 gradient buffer) and `bn_bwd_apply`
+// Backward mirrors it: `bn_bwd_reduce` (ReLU mask from the saved output, dgamma / dbeta
+// partials), `bn_bwd_finalize` (writes dgamma / dbeta into the flat fp32 gradient buffer),
+// `bn_bwd_apply`
 //   dy = gamma * invstd * (g - dbeta/P - xhat * dgamma/P),   g = dz masked by ReLU
-// which also emits g itself as the gradient of the residual branch when asked.
+// which also emits g itself as the gradient of the residual branch when asked.  The sums are
+// deterministic (fixed partition, fixed order).
 //
 // All kernels are bandwidth bound: every thread moves 16 bytes (8 channels) per access, a row
 // of C channels is covered by C/8 consecutive lanes, and a block walks rows grid-strided.
@@ -24,12 +28,14 @@
 namespace {
 
 constexpr int TPB = 256;
+constexpr int MAX_PARTIAL_BLOCKS = 512;   // rows of the partial-sum workspace
 
-// Sum the per-thread partials of threads that own the same channel chunk (same tid % tpr) and
-// add the block result to global memory. part[] has NV values per thread.
+// Per-block partial sums: threads that own the same channel chunk (same tid % tpr) are summed
+// through LDS and the block writes one row [NV/8 quantities][C] of the workspace with plain
+// stores.  No atomics: thousands of blocks adding to the same few addresses serialise in L2.
 template <int NV>
-__device__ __forceinline__ void block_reduce_to_global(float (&part)[NV], int tpr, int chunk,
-                                                       int rowid, float* const* dst, int C) {
+__device__ __forceinline__ void block_reduce_to_partials(float (&part)[NV], int tpr, int chunk,
+                                                         int rowid, float* ws_row, int C) {
   __shared__ float red[TPB * NV];
   const int tid = threadIdx.x;
   const int rpb = TPB / tpr;
@@ -47,25 +53,42 @@ __device__ __forceinline__ void block_reduce_to_global(float (&part)[NV], int tp
     }
   }
   if (rowid == 0) {
-    // NV = 8 channels x (NV/8) quantities
 #pragma unroll
-    for (int qn = 0; qn < NV / 8; ++qn)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int ch = chunk * 8 + c;
-        if (ch < C) atomicAdd(dst[qn] + ch, part[qn * 8 + c]);
-      }
+    for (int qn = 0; qn < NV / 8; ++qn) {
+      f32x4 lo = {part[qn * 8 + 0], part[qn * 8 + 1], part[qn * 8 + 2], part[qn * 8 + 3]};
+      f32x4 hi = {part[qn * 8 + 4], part[qn * 8 + 5], part[qn * 8 + 6], part[qn * 8 + 7]};
+      *reinterpret_cast<f32x4*>(ws_row + qn * C + chunk * 8) = lo;
+      *reinterpret_cast<f32x4*>(ws_row + qn * C + chunk * 8 + 4) = hi;
+    }
   }
 }
 
-__global__ __launch_bounds__(TPB) void bn_stats_kernel(const bf16_t* __restrict__ y, float* sum,
-                                                       float* sqsum, int P, int C) {
+__global__ __launch_bounds__(TPB) void bn_stats_kernel(const bf16_t* __restrict__ y,
+                                                       float* __restrict__ ws, int P, int C) {
   const int tpr = C >> 3, rpb = TPB / tpr;
   const int chunk = threadIdx.x % tpr, rowid = threadIdx.x / tpr;
   float part[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) part[i] = 0.f;
-  for (int row = blockIdx.x * rpb + rowid; row < P; row += gridDim.x * rpb) {
+  const int stride = gridDim.x * rpb;
+  int row = blockIdx.x * rpb + rowid;
+  for (; row + 3 * stride < P; row += 4 * stride) {     // four independent 16-byte loads in flight
+    u32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      v[u] = *reinterpret_cast<const u32x4*>(y + (size_t)(row + u * stride) * C + chunk * 8);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float f[8];
+      unpack8(v[u], f);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        part[c] += f[c];
+        part[8 + c] += f[c] * f[c];
+      }
+    }
+  }
+  for (; row < P; row += stride) {
     const u32x4 v = *reinterpret_cast<const u32x4*>(y + (size_t)row * C + chunk * 8);
     float f[8];
     unpack8(v, f);
@@ -75,42 +98,87 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const bf16_t* __restrict_
       part[8 + c] += f[c] * f[c];
     }
   }
-  float* dst[2] = {sum, sqsum};
-  block_reduce_to_global<16>(part, tpr, chunk, rowid, dst, C);
+  block_reduce_to_partials<16>(part, tpr, chunk, rowid, ws + (size_t)blockIdx.x * 2 * C, C);
+}
+
+// Sums the G partial rows of the workspace: column j of [G][cols]. 32 columns per block,
+// 8 row lanes per column; 8 independent loads in flight per thread (the loop is latency bound).
+__device__ __forceinline__ float column_sum(const float* __restrict__ ws, int G, int cols, int col,
+                                            int rl, float* red) {
+  float s = 0.f;
+  if (col < cols) {
+    const float* p = ws + col;
+    int g = rl;
+    for (; g + 56 < G; g += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(g + 8 * u) * cols];
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; g < G; g += 8) s += p[(size_t)g * cols];
+  }
+  red[rl * 32 + (threadIdx.x & 31)] = s;
+  __syncthreads();
+  float t = 0.f;
+  if (rl == 0) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r * 32 + (threadIdx.x & 31)];
+  }
+  __syncthreads();
+  return t;
+}
+
+struct BnFinalizeArgs {
+  const float* ws; int G;
+  const float* gamma; const float* beta; float* mm; float* mv;
+  float* save_mean; float* save_invstd; float* scale; float* shift;
+  int P, C; float eps, momentum;
+};
+
+// One block per 32 channels: mean / variance from the partial sums, scale / shift for the
+// apply sweep, saved statistics for backward, moving-average update.
+__global__ __launch_bounds__(TPB) void bn_fwd_finalize_kernel(const BnFinalizeArgs a) {
+  __shared__ float red[256];
+  const int ch = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+  const float s1 = column_sum(a.ws, a.G, 2 * a.C, ch, rl, red);
+  const float s2 = column_sum(a.ws, a.G, 2 * a.C, a.C + ch, rl, red);
+  if (rl == 0 && ch < a.C) {
+    const float invP = 1.f / (float)a.P;
+    const float mean = s1 * invP;
+    const float var = fmaxf(s2 * invP - mean * mean, 0.f);
+    const float invstd = rsqrtf(var + a.eps);
+    const float sc = a.gamma[ch] * invstd;
+    a.scale[ch] = sc;
+    a.shift[ch] = a.beta[ch] - mean * sc;
+    a.save_mean[ch] = mean;
+    a.save_invstd[ch] = invstd;
+    const float unbiased = a.P > 1 ? var * ((float)a.P / (float)(a.P - 1)) : var;
+    a.mm[ch] = a.mm[ch] * a.momentum + mean * (1.f - a.momentum);
+    a.mv[ch] = a.mv[ch] * a.momentum + unbiased * (1.f - a.momentum);
+  }
 }
 
 struct BnApplyArgs {
   const bf16_t* y; const bf16_t* res; bf16_t* z;
-  const float* sum; const float* sqsum; const float* gamma; const float* beta;
-  float* mm; float* mv; float* save_mean; float* save_invstd;
-  int P, C; float eps, momentum; int relu, training;
+  const float* scale; const float* shift;        // training: produced by the finalize kernel
+  const float* gamma; const float* beta; const float* mm; const float* mv;   // inference
+  int P, C; float eps; int relu;
 };
 
 __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
   const int C = a.C, tpr = C >> 3, rpb = TPB / tpr;
   const int chunk = threadIdx.x % tpr, rowid = threadIdx.x / tpr;
   float scale[8], shift[8];
-  const float invP = 1.f / (float)a.P;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int ch = chunk * 8 + c;
-    float mean, var;
-    if (a.training) {
-      mean = a.sum[ch] * invP;
-      var = fmaxf(a.sqsum[ch] * invP - mean * mean, 0.f);
+    if (a.scale) {
+      scale[c] = a.scale[ch];
+      shift[c] = a.shift[ch];
     } else {
-      mean = a.mm[ch];
-      var = a.mv[ch];
-    }
-    const float invstd = rsqrtf(var + a.eps);
-    scale[c] = a.gamma[ch] * invstd;
-    shift[c] = a.beta[ch] - mean * scale[c];
-    if (a.training && blockIdx.x == 0 && rowid == 0) {
-      a.save_mean[ch] = mean;
-      a.save_invstd[ch] = invstd;
-      const float unbiased = a.P > 1 ? var * ((float)a.P / (float)(a.P - 1)) : var;
-      a.mm[ch] = a.mm[ch] * a.momentum + mean * (1.f - a.momentum);
-      a.mv[ch] = a.mv[ch] * a.momentum + unbiased * (1.f - a.momentum);
+      const float invstd = rsqrtf(a.mv[ch] + a.eps);
+      scale[c] = a.gamma[ch] * invstd;
+      shift[c] = a.beta[ch] - a.mm[ch] * scale[c];
     }
   }
   for (int row = blockIdx.x * rpb + rowid; row < a.P; row += gridDim.x * rpb) {
@@ -138,6 +206,7 @@ struct BnBwdArgs {
   const float* mean; const float* invstd; const float* gamma;
   float* dgamma; float* dbeta;
   bf16_t* dy; bf16_t* dres;
+  float* ws; int G;
   int P, C;
 };
 
@@ -170,8 +239,18 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
       part[8 + c] += g[c];                                  // dbeta
     }
   }
-  float* dst[2] = {a.dgamma, a.dbeta};
-  block_reduce_to_global<16>(part, tpr, chunk, rowid, dst, C);
+  block_reduce_to_partials<16>(part, tpr, chunk, rowid, a.ws + (size_t)blockIdx.x * 2 * C, C);
+}
+
+__global__ __launch_bounds__(TPB) void bn_bwd_finalize_kernel(const BnBwdArgs a) {
+  __shared__ float red[256];
+  const int ch = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+  const float dg = column_sum(a.ws, a.G, 2 * a.C, ch, rl, red);
+  const float db = column_sum(a.ws, a.G, 2 * a.C, a.C + ch, rl, red);
+  if (rl == 0 && ch < a.C) {
+    a.dgamma[ch] = dg;     // plain stores into the flat gradient buffer
+    a.dbeta[ch] = db;
+  }
 }
 
 __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
@@ -222,31 +301,48 @@ int rows_grid(int P, int C) {
   return blocks < 2048 ? blocks : 2048;
 }
 
-}  // namespace
-
-void launch_bn_stats(const bf16_t* y, float* sum, float* sqsum, int P, int C, hipStream_t s) {
-  check_channels(C, P);
-  int grid = rows_grid(P, C);
-  if (grid > 1024) grid = 1024;     // bounds the atomics per channel
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(TPB), 0, s, y, sum, sqsum, P, C);
+// Reduction grid: enough blocks to pull full HBM bandwidth, at least 8 row passes per block,
+// bounded by the rows of the workspace.
+int reduce_grid(int P, int C) {
+  const int rpb = TPB / (C / 8);
+  int blocks = (P + rpb * 8 - 1) / (rpb * 8);
+  if (blocks < 1) blocks = 1;
+  return blocks < MAX_PARTIAL_BLOCKS ? blocks : MAX_PARTIAL_BLOCKS;
 }
 
-void launch_bn_apply(const bf16_t* y, const bf16_t* res, bf16_t* z, const float* sum,
-                     const float* sqsum, const float* gamma, const float* beta, float* mm,
-                     float* mv, float* save_mean, float* save_invstd, int P, int C, float eps,
-                     float momentum, int relu, int training, hipStream_t s) {
+}  // namespace
+
+size_t bn_workspace_floats() { return (size_t)MAX_PARTIAL_BLOCKS * 2 * 2048; }
+
+void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, const float* gamma,
+                         const float* beta, float* mm, float* mv, float* save_mean,
+                         float* save_invstd, float* scale, float* shift, float* ws, int P, int C,
+                         float eps, float momentum, int relu, hipStream_t s) {
   check_channels(C, P);
-  BnApplyArgs a{y, res, z, sum, sqsum, gamma, beta, mm, mv, save_mean, save_invstd,
-                P, C, eps, momentum, relu, training};
+  const int G = reduce_grid(P, C);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(G), dim3(TPB), 0, s, y, ws, P, C);
+  BnFinalizeArgs f{ws, G, gamma, beta, mm, mv, save_mean, save_invstd, scale, shift,
+                   P, C, eps, momentum};
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 31) / 32), dim3(TPB), 0, s, f);
+  BnApplyArgs a{y, res, z, scale, shift, gamma, beta, mm, mv, P, C, eps, relu};
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
+}
+
+void launch_bn_infer(const bf16_t* y, const bf16_t* res, bf16_t* z, const float* gamma,
+                     const float* beta, const float* mm, const float* mv, int P, int C, float eps,
+                     int relu, hipStream_t s) {
+  check_channels(C, P);
+  BnApplyArgs a{y, res, z, nullptr, nullptr, gamma, beta, mm, mv, P, C, eps, relu};
   hipLaunchKernelGGL(bn_apply_kernel, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
 }
 
 void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const float* mean,
                    const float* invstd, const float* gamma, float* dgamma, float* dbeta,
-                   bf16_t* dy, bf16_t* dres, int P, int C, hipStream_t s) {
+                   bf16_t* dy, bf16_t* dres, float* ws, int P, int C, hipStream_t s) {
   check_channels(C, P);
-  BnBwdArgs a{dz, y, z, mean, invstd, gamma, dgamma, dbeta, dy, dres, P, C};
-  int grid = rows_grid(P, C);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid > 1024 ? 1024 : grid), dim3(TPB), 0, s, a);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(TPB), 0, s, a);
+  const int G = reduce_grid(P, C);
+  BnBwdArgs a{dz, y, z, mean, invstd, gamma, dgamma, dbeta, dy, dres, ws, G, P, C};
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(G), dim3(TPB), 0, s, a);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(TPB), 0, s, a);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
 }

@@ -2,14 +2,17 @@
 #pragma once
 #include "common.h"
 
-void launch_bn_stats(const bf16_t* y, float* sum, float* sqsum, int P, int C, hipStream_t s);
-void launch_bn_apply(const bf16_t* y, const bf16_t* res, bf16_t* z, const float* sum,
-                     const float* sqsum, const float* gamma, const float* beta, float* mm,
-                     float* mv, float* save_mean, float* save_invstd, int P, int C, float eps,
-                     float momentum, int relu, int training, hipStream_t s);
+size_t bn_workspace_floats();
+void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, const float* gamma,
+                         const float* beta, float* mm, float* mv, float* save_mean,
+                         float* save_invstd, float* scale, float* shift, float* ws, int P, int C,
+                         float eps, float momentum, int relu, hipStream_t s);
+void launch_bn_infer(const bf16_t* y, const bf16_t* res, bf16_t* z, const float* gamma,
+                     const float* beta, const float* mm, const float* mv, int P, int C, float eps,
+                     int relu, hipStream_t s);
 void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const float* mean,
                    const float* invstd, const float* gamma, float* dgamma, float* dbeta,
-                   bf16_t* dy, bf16_t* dres, int P, int C, hipStream_t s);
+                   bf16_t* dy, bf16_t* dres, float* ws, int P, int C, hipStream_t s);
 
 void launch_maxpool_fwd(const bf16_t* x, bf16_t* out, uint8_t* idx, int N, int H, int W, int C,
                         int OH, int OW, int k, int stride, int pt, int pl, hipStream_t s);

@@ -179,22 +179,22 @@ def test_batchnorm_fwd_bwd(C, relu, residual):
   native = _native()
   dev = torch.device("cuda")
   gen = torch.Generator().manual_seed(C)
-  P = 8 * 7 * 7
+  P = 64 * 7 * 7 + 3
   y = _bf(torch.randn(P, C, generator=gen) * 2 + 0.5).to(dev)
   res = _bf(torch.randn(P, C, generator=gen)).to(dev) if residual else None
   gamma = (torch.rand(C, generator=gen) + 0.5).to(dev)
   beta = (torch.randn(C, generator=gen) * 0.1).to(dev)
   mm = torch.zeros(C, device=dev)
   mv = torch.ones(C, device=dev)
-  stats = torch.zeros(2 * C, device=dev)
-  saved = torch.zeros(2 * C, device=dev)
+  saved = torch.zeros(4 * C, device=dev)
+  ws = torch.zeros(native.ext().bn_workspace_floats(), device=dev)
   z = torch.empty(P, C, dtype=torch.bfloat16, device=dev)
-  native.run_op("bn_stats", dict(y=y.data_ptr(), sum=stats.data_ptr(), sqsum=stats.data_ptr() + 4 * C, P=P, C=C))
-  native.run_op("bn_apply", dict(y=y.data_ptr(), res=res.data_ptr() if residual else None, z=z.data_ptr(),
-                                 sum=stats.data_ptr(), sqsum=stats.data_ptr() + 4 * C, gamma=gamma.data_ptr(),
-                                 beta=beta.data_ptr(), mm=mm.data_ptr(), mv=mv.data_ptr(),
-                                 save_mean=saved.data_ptr(), save_invstd=saved.data_ptr() + 4 * C,
-                                 P=P, C=C, eps=1e-5, momentum=0.9, relu=int(relu), training=1))
+  native.run_op("bn_fwd_train", dict(
+      y=y.data_ptr(), res=res.data_ptr() if residual else None, z=z.data_ptr(),
+      gamma=gamma.data_ptr(), beta=beta.data_ptr(), mm=mm.data_ptr(), mv=mv.data_ptr(),
+      save_mean=saved.data_ptr(), save_invstd=saved.data_ptr() + 4 * C,
+      scale=saved.data_ptr() + 8 * C, shift=saved.data_ptr() + 12 * C, ws=ws.data_ptr(),
+      P=P, C=C, eps=1e-5, momentum=0.9, relu=int(relu)))
   torch.cuda.synchronize()
   yr = y.float().requires_grad_(True)
   gr = gamma.clone().requires_grad_(True)
@@ -226,7 +226,7 @@ def test_batchnorm_fwd_bwd(C, relu, residual):
   native.run_op("bn_bwd", dict(dz=dz.data_ptr(), y=y.data_ptr(), z=z.data_ptr() if relu else None,
                                mean=saved.data_ptr(), invstd=saved.data_ptr() + 4 * C, gamma=gamma.data_ptr(),
                                dgamma=dgamma.data_ptr(), dbeta=dbeta.data_ptr(), dy=dy.data_ptr(),
-                               dres=dres.data_ptr() if residual else None, P=P, C=C))
+                               dres=dres.data_ptr() if residual else None, ws=ws.data_ptr(), P=P, C=C))
   torch.cuda.synchronize()
   assert torch.allclose(dgamma, dgamma_ref, rtol=1e-2, atol=5e-2)
   assert torch.allclose(dbeta, dbeta_ref, rtol=1e-2, atol=5e-2)
@@ -235,10 +235,9 @@ def test_batchnorm_fwd_bwd(C, relu, residual):
     assert torch.equal(dres.float(), _bf(g).float())
   # inference mode uses the moving statistics
   z2 = torch.empty_like(z)
-  native.run_op("bn_apply", dict(y=y.data_ptr(), res=None, z=z2.data_ptr(), sum=None, sqsum=None,
-                                 gamma=gamma.data_ptr(), beta=beta.data_ptr(), mm=mm.data_ptr(), mv=mv.data_ptr(),
-                                 save_mean=None, save_invstd=None, P=P, C=C, eps=1e-5, momentum=0.9,
-                                 relu=0, training=0))
+  native.run_op("bn_infer", dict(y=y.data_ptr(), res=None, z=z2.data_ptr(), gamma=gamma.data_ptr(),
+                                 beta=beta.data_ptr(), mm=mm.data_ptr(), mv=mv.data_ptr(), P=P, C=C,
+                                 eps=1e-5, relu=0))
   torch.cuda.synchronize()
   ref2 = (y.float() - mm) * torch.rsqrt(mv + 1e-5) * gamma + beta
   assert torch.allclose(z2.float(), ref2, rtol=2e-2, atol=2e-2)
