@@ -57,7 +57,7 @@ def launch(argv: Sequence[str], nproc: int, num_ps: int = 0, master_addr: str = 
                   "MASTER_PORT": str(master_port), "DTF_NUM_PS": str(num_ps),
                   "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
       if env_extra:
-        env.update(env_extra)
+        env.update(env_extra)        # may pin LOCAL_RANK (several ranks on one GPU in tests)
       stderr = None
       if log_dir:
         f = open(os.path.join(log_dir, "log%d.log" % rank), "w")

@@ -231,8 +231,7 @@ Launch make_op(const std::string& kind, const py::dict& d) {
   if (kind == "memset") {
     auto p = ptr<uint8_t>(d, "ptr");
     const size_t n = get<size_t>(d, "nbytes");
-    const int value = get_or<int>(d, "value", 0);
-    return [=](hipStream_t s) { HIP_CHECK(hipMemsetAsync(p, value, n, s)); };
+    return [=](hipStream_t s) { launch_zero(p, n, s); };
   }
   throw std::invalid_argument("unknown op kind '" + kind + "'");
 }

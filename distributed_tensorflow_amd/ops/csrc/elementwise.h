@@ -48,4 +48,5 @@ void launch_pack_weights(const float* params, bf16_t* packed, const PackDesc* de
 
 void launch_preprocess_pad(const float* in, bf16_t* out, int N, int H, int W, int Cin, int pt,
                            int pl, int OH, int OW, int Cpad, hipStream_t s);
+void launch_zero(void* ptr, size_t nbytes, hipStream_t s);
 void launch_cast_f32_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);

@@ -124,6 +124,18 @@ __global__ __launch_bounds__(256) void preprocess_pad_kernel(const float* __rest
   }
 }
 
+// Zero fill as a kernel (not hipMemsetAsync): inside a captured hipGraph a large memset node
+// was observed to race with the atomics of the kernel that follows it; a kernel node is
+// ordered like every other launch.
+__global__ __launch_bounds__(256) void zero_kernel(u32x4* __restrict__ p, size_t n16,
+                                                   uint8_t* __restrict__ tail, int ntail) {
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16;
+       i += (size_t)gridDim.x * blockDim.x)
+    p[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ in,
                                                    bf16_t* __restrict__ out, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
@@ -160,6 +172,15 @@ void launch_preprocess_pad(const float* in, bf16_t* out, int N, int H, int W, in
   if (Cpad < Cin) throw std::invalid_argument("preprocess_pad: Cpad < Cin");
   hipLaunchKernelGGL(preprocess_pad_kernel, dim3(grid_for((size_t)N * OH * OW)), dim3(256), 0, s,
                      in, out, N, H, W, Cin, pt, pl, OH, OW, Cpad);
+}
+
+void launch_zero(void* ptr, size_t nbytes, hipStream_t s) {
+  if ((uintptr_t)ptr & 15) throw std::invalid_argument("zero fill: pointer must be 16-byte aligned");
+  const size_t n16 = nbytes / 16;
+  const int ntail = (int)(nbytes - n16 * 16);
+  hipLaunchKernelGGL(zero_kernel, dim3(grid_for(n16 ? n16 : 1)), dim3(256), 0, s,
+                     reinterpret_cast<u32x4*>(ptr), n16,
+                     reinterpret_cast<uint8_t*>(ptr) + n16 * 16, ntail);
 }
 
 void launch_cast_f32_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {

@@ -133,7 +133,9 @@ def get_communicator(task: Optional[TaskInfo] = None, use_gpu: bool = True,
     return _COMM
   task = task or resolve_task()
   device = _pick_device(task.local_rank, use_gpu)
-  backend = backend or ("nccl" if device.type == "cuda" else "gloo")
+  # DTF_BACKEND overrides the choice (e.g. gloo to run several ranks on one GPU in tests)
+  backend = backend or os.environ.get("DTF_BACKEND") or (
+      "nccl" if device.type == "cuda" else "gloo")
   owns = False
   if task.world_size > 1 and not dist.is_initialized():
     init_method = "tcp://%s:%d" % (task.master_addr, task.master_port)

@@ -142,7 +142,9 @@ class Model:
 
   # -- label handling -----------------------------------------------------------------
   def _class_indices(self, labels: torch.Tensor) -> torch.Tensor:
-    if self.loss == "categorical_crossentropy":
+    if self.loss == "categorical_crossentropy" and not (labels.dim() == 2 and labels.shape[1] == 1):
+      # one-hot targets; a [N, 1] tensor is the synthetic-data label format the reference
+      # feeds to both drivers (common.py:344-350) and is taken as class indices
       if labels.dim() != 2:
         raise ValueError("categorical_crossentropy expects one-hot labels [N, classes]")
       return labels.argmax(dim=1).long()
@@ -155,6 +157,8 @@ class Model:
   def train_on_batch(self, images: torch.Tensor, labels: torch.Tensor):
     """Runs one optimisation step; returns (mean loss tensor, correct-count tensor)."""
     st = self.strategy
+    if not self._synced_initial:
+      self._sync_initial_variables()
     ex = self._executor(int(images.shape[0]))
     idx = self._class_indices(labels.to(self.device))
     if st is not None and not st.synchronous:
@@ -194,7 +198,8 @@ class Model:
       return history
     if steps_per_epoch is None:
       steps_per_epoch = len(x)  # type: ignore[arg-type]
-    cbs = CallbackList([history] + list(callbacks or []), self,
+    # History goes last (as in Keras) so it records what earlier callbacks put into `logs`
+    cbs = CallbackList(list(callbacks or []) + [history], self,
                        dict(epochs=epochs, steps=steps_per_epoch, verbose=verbose))
     self._sync_initial_variables()
     self.stop_training = False

@@ -13,7 +13,8 @@ import sys
 
 from distributed_tensorflow_amd import common
 from distributed_tensorflow_amd.data import imagenet_preprocessing
-from distributed_tensorflow_amd.models import resnet_model, trivial_model
+from distributed_tensorflow_amd.models import resnet_model
+from distributed_tensorflow_amd.models.trivial_model import trivial_model as build_trivial_model
 from distributed_tensorflow_amd.train import driver
 from distributed_tensorflow_amd.train.schedules import (IMAGENET_LR_SCHEDULE as LR_SCHEDULE,
                                                         imagenet_learning_rate_schedule)
@@ -34,7 +35,7 @@ def dataset_config() -> driver.DatasetConfig:
       num_classes=imagenet_preprocessing.NUM_CLASSES,
       num_images=imagenet_preprocessing.NUM_IMAGES,
       model_fn=lambda: resnet_model.resnet50(num_classes=imagenet_preprocessing.NUM_CLASSES),
-      trivial_model_fn=lambda: trivial_model.trivial_model(imagenet_preprocessing.NUM_CLASSES),
+      trivial_model_fn=lambda: build_trivial_model(imagenet_preprocessing.NUM_CLASSES),
       loss="sparse_categorical_crossentropy",
       accuracy_metric="sparse_categorical_accuracy",
       learning_rate_schedule=learning_rate_schedule,

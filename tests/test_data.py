@@ -1,0 +1,160 @@
+"""Input pipelines on small generated files (CIFAR-10 binary records, ImageNet TFRecords)."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from distributed_tensorflow_amd.data import cifar_preprocessing as cifar
+from distributed_tensorflow_amd.data import imagenet_preprocessing as imnet
+from distributed_tensorflow_amd.data.synthetic import get_synth_input_fn
+from distributed_tensorflow_amd.utils import tfrecord
+
+
+def _write_cifar(dirname, per_file=24):
+  rng = np.random.default_rng(0)
+  os.makedirs(dirname, exist_ok=True)
+  names = ["data_batch_%d.bin" % i for i in range(1, 6)] + ["test_batch.bin"]
+  k = 0
+  for n in names:
+    with open(os.path.join(dirname, n), "wb") as f:
+      for _ in range(per_file):
+        label = k % 10
+        img = rng.integers(0, 256, size=3072, dtype=np.uint8)
+        img[0] = k % 256                    # tag the record so duplicates are detectable
+        f.write(bytes([label]) + img.tobytes())
+        k += 1
+  return names
+
+
+def test_cifar_parse_and_preprocess():
+  raw = bytes([7]) + np.arange(3072, dtype=np.uint32).astype(np.uint8).tobytes()
+  img, lab = cifar.parse_record(raw, is_training=False)
+  assert img.shape == (32, 32, 3) and img.dtype == np.float32
+  assert lab.tolist() == [0, 0, 0, 0, 0, 0, 0, 1, 0, 0]
+  # CHW -> HWC: pixel (0,0) holds bytes 0, 1024, 2048 before standardisation
+  assert abs(img.mean()) < 1e-5 and abs(img.std() - 1.0) < 1e-3
+  a, _ = cifar.parse_record(raw, True, rng=np.random.default_rng(1))
+  b, _ = cifar.parse_record(raw, True, rng=np.random.default_rng(2))
+  assert a.shape == (32, 32, 3) and not np.array_equal(a, b)       # random crop / flip
+
+
+@pytest.mark.parametrize("workers", [0, 2])
+def test_cifar_input_fn(tmp_path, workers):
+  _write_cifar(str(tmp_path))
+  ds = cifar.input_fn(True, str(tmp_path), batch_size=8, datasets_num_private_threads=workers,
+                      drop_remainder=True)
+  it = iter(ds)
+  for _ in range(3):
+    x, y = next(it)
+    assert tuple(x.shape) == (8, 32, 32, 3) and x.dtype == torch.float32
+    assert tuple(y.shape) == (8, 10) and torch.all(y.sum(1) == 1)
+  ev = cifar.input_fn(False, str(tmp_path), batch_size=6, datasets_num_private_threads=workers)
+  n = sum(x.shape[0] for x, _ in ev)
+  assert n == 24                                            # one pass over test_batch.bin
+
+
+def test_cifar_sharding_is_disjoint(tmp_path):
+  _write_cifar(str(tmp_path))
+  seen = []
+  for shard in range(2):
+    ev = cifar.input_fn(False, str(tmp_path), batch_size=4, datasets_num_private_threads=0,
+                        shard_index=shard, num_shards=2)
+    seen.append(sum(x.shape[0] for x, _ in ev))
+  assert seen == [12, 12]
+
+
+def _jpeg(h, w, seed):
+  from PIL import Image
+  rng = np.random.default_rng(seed)
+  arr = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+  buf = io.BytesIO()
+  Image.fromarray(arr).save(buf, format="JPEG", quality=90)
+  return buf.getvalue()
+
+
+def _write_imagenet(dirname, nfiles=3, per_file=5):
+  files = []
+  k = 0
+  for i in range(nfiles):
+    p = os.path.join(dirname, "train-%05d-of-01024" % i)
+    with open(p, "wb") as f:
+      for _ in range(per_file):
+        ex = tfrecord.encode_example({
+            "image/encoded": _jpeg(300 + 10 * k, 400, k),
+            "image/class/label": [k + 1],
+            "image/class/text": b"thing",
+            "image/object/bbox/xmin": [0.1], "image/object/bbox/ymin": [0.2],
+            "image/object/bbox/xmax": [0.9], "image/object/bbox/ymax": [0.8]})
+        tfrecord.write_record(f, ex)
+        k += 1
+    files.append(p)
+  return files
+
+
+def test_tfrecord_and_example_codec(tmp_path):
+  assert tfrecord.crc32c(b"123456789") == 0xE3069283         # CRC-32C check value
+  p = tmp_path / "x.tfrecord"
+  ex = tfrecord.encode_example({"a": b"bytes", "b": [1, -2, 3], "c": [0.5, 1.5]})
+  with open(p, "wb") as f:
+    tfrecord.write_record(f, ex)
+    tfrecord.write_record(f, b"")
+  with open(p, "rb") as f:
+    recs = list(tfrecord.read_records(f, verify=True))
+  assert recs[1] == b""
+  d = tfrecord.decode_example(recs[0])
+  assert d["a"] == [b"bytes"] and d["b"] == [1, -2, 3] and d["c"] == pytest.approx([0.5, 1.5])
+  bad = bytearray(open(p, "rb").read())
+  bad[14] ^= 0xFF
+  with pytest.raises(IOError):
+    list(tfrecord.read_records(io.BytesIO(bytes(bad)), verify=True))
+
+
+def test_imagenet_parse_record(tmp_path):
+  files = _write_imagenet(str(tmp_path), 1, 2)
+  with open(files[0], "rb") as f:
+    rec = next(tfrecord.read_records(f))
+  img, lab = imnet.parse_record(rec, is_training=True, rng=np.random.default_rng(0))
+  assert img.shape == (224, 224, 3) and img.dtype == np.float32
+  assert lab.tolist() == [0.0] and lab.dtype == np.float32         # label - 1, float32, shape [1]
+  ev, _ = imnet.parse_record(rec, is_training=False)
+  assert ev.shape == (224, 224, 3)
+  # mean subtraction: values are centred around zero, inside [-124, 152]
+  assert -124.0 <= ev.min() and ev.max() <= 152.0
+  ev2, _ = imnet.parse_record(rec, is_training=False)
+  assert np.array_equal(ev, ev2)                                    # eval path is deterministic
+
+
+def test_sample_distorted_bounding_box_constraints():
+  rng = np.random.default_rng(0)
+  box = np.array([[0.2, 0.1, 0.8, 0.9]], dtype=np.float32)
+  for _ in range(200):
+    y, x, h, w = imnet.sample_distorted_bounding_box(300, 400, box, rng)
+    assert 0 <= y and y + h <= 300 and 0 <= x and x + w <= 400
+    assert 0.05 * 300 * 400 * 0.9 <= h * w <= 300 * 400
+    assert 0.74 <= w / h <= 1.34
+  assert imnet._smallest_size_at_least(300, 400, 256) == (256, 341)
+
+
+def test_imagenet_input_fn(tmp_path):
+  files = _write_imagenet(str(tmp_path))
+  ds = imnet.input_fn(True, str(tmp_path), batch_size=4, datasets_num_private_threads=2,
+                      drop_remainder=True, filenames=files)
+  it = iter(ds)
+  x, y = next(it)
+  assert tuple(x.shape) == (4, 224, 224, 3) and tuple(y.shape) == (4, 1)
+  assert y.min() >= 0 and y.max() < 15
+  assert len(imnet.get_filenames(True, "/d")) == 1024 and len(imnet.get_filenames(False, "/d")) == 128
+  assert imnet.get_filenames(True, "/d")[5] == "/d/train-00005-of-01024"
+
+
+def test_synthetic_input_matches_reference_contract():
+  fn = get_synth_input_fn(224, 224, 3, 1001)
+  ds = fn(True, None, 4)
+  x, y = next(iter(ds))
+  assert tuple(x.shape) == (4, 224, 224, 3) and tuple(y.shape) == (4, 1) and y.dtype == torch.float32
+  assert torch.equal(x[0], x[3]) and 0 <= y[0, 0] < 1000        # one sample repeated; last class never used
+  assert 0 <= x.min() and x.max() <= 255
+  x2, _ = next(iter(ds))
+  assert x2.data_ptr() == x.data_ptr()                           # same resident batch every step

@@ -1,0 +1,255 @@
+"""Multi-process tests of the distribution strategies on CPU (`gloo`, world size 2-3).
+
+They use the framework's own launcher to start one process per rank on localhost - the
+same trick the reference uses for manual testing (two terminals with `localhost:8080/8081`,
+`README.md:120-124`) - and check what the reference never tests automatically: gradient
+equality across replicas, equivalence of N-replica training with single-process large-batch
+training, Horovod-API semantics, and parameter-server push/pull.
+"""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_ranks(tmp_path, body: str, nproc: int, num_ps: int = 0, timeout: int = 300):
+  """Writes `body` as a script and runs it under the launcher; returns per-rank JSON results."""
+  script = tmp_path / "worker.py"
+  script.write_text("import sys, os, json\nsys.path.insert(0, %r)\n" % ROOT +
+                    "import torch\ntorch.set_num_threads(1)\n" + textwrap.dedent(body))
+  sys.path.insert(0, ROOT)
+  from distributed_tensorflow_amd import launch
+  env = {"DTF_TEST_OUT": str(tmp_path), "OMP_NUM_THREADS": "1"}
+  code = launch.launch([str(script)], nproc, num_ps=num_ps, log_dir=str(tmp_path / "logs"),
+                       env_extra=env, timeout_s=timeout)
+  logs = ""
+  for i in range(nproc):
+    p = tmp_path / "logs" / ("log%d.log" % i)
+    if p.exists():
+      logs += "\n--- rank %d ---\n" % i + p.read_text()[-3000:]
+  assert code == 0, logs
+  out = []
+  for i in range(nproc):
+    p = tmp_path / ("result%d.json" % i)
+    out.append(json.loads(p.read_text()) if p.exists() else None)
+  return out
+
+
+COMMON = """
+from distributed_tensorflow_amd import models
+from distributed_tensorflow_amd.parallel import strategy as S, cluster
+from distributed_tensorflow_amd.train.model import Model
+from distributed_tensorflow_amd.train.optimizers import SGD
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+def save(obj):
+  with open(os.path.join(os.environ["DTF_TEST_OUT"], "result%d.json" % rank), "w") as f:
+    json.dump(obj, f)
+g = torch.Generator().manual_seed(123)
+X = torch.randn(8, 32, 32, 3, generator=g) * 50 + 100
+Y = torch.randint(0, 10, (8, 1), generator=g).float()
+"""
+
+
+@pytest.mark.parametrize("alg,packs", [(None, 1), ("hierarchical_copy", 3), ("ring", 0)])
+def test_mirrored_matches_single_process_large_batch(tmp_path, alg, packs):
+  body = COMMON + """
+strat = S.get_distribution_strategy("mirrored", num_gpus=0, all_reduce_alg=%r, num_packs=%d)
+assert strat.num_replicas_in_sync == world
+m = Model(models.resnet20(), strategy=strat, dtype="fp32", seed=5 + rank)   # different seeds: broadcast must fix it
+m.compile(SGD(0.05, momentum=0.9), "sparse_categorical_crossentropy", ["sparse_categorical_accuracy"])
+per = strat.per_replica_batch_size(8)
+xs, ys = X[rank * per:(rank + 1) * per], Y[rank * per:(rank + 1) * per]
+m._sync_initial_variables()
+p0 = m.store.params.clone()
+losses = []
+for _ in range(3):
+  l, c = m.train_on_batch(xs, ys)
+  losses.append(l.item())
+save({"params_sum": m.store.params.double().sum().item(), "p0_sum": p0.double().sum().item(),
+      "fc": m.store.view("fc10/kernel").flatten()[:16].tolist(),
+      "conv1": m.store.view("conv1/kernel").flatten()[:16].tolist(),
+      "grad_head": m.store.grads[:32].tolist(), "losses": losses,
+      "collectives": m._grad_reducer().collectives_launched})
+strat.barrier()
+""" % (alg, packs)
+  res = _run_ranks(tmp_path, body, 2)
+  # replicas hold identical variables and identical (reduced) gradients
+  assert res[0]["p0_sum"] == res[1]["p0_sum"]
+  assert res[0]["fc"] == res[1]["fc"] and res[0]["conv1"] == res[1]["conv1"]
+  assert res[0]["grad_head"] == res[1]["grad_head"]
+  assert res[0]["collectives"] > 0
+  # single process, global batch 8, same initial weights (seed 5 = rank 0's)
+  sys.path.insert(0, ROOT)
+  from distributed_tensorflow_amd import models
+  from distributed_tensorflow_amd.train.model import Model
+  from distributed_tensorflow_amd.train.optimizers import SGD
+  torch.set_num_threads(1)
+  g = torch.Generator().manual_seed(123)
+  X = torch.randn(8, 32, 32, 3, generator=g) * 50 + 100
+  Y = torch.randint(0, 10, (8, 1), generator=g).float()
+  m = Model(models.resnet20(), dtype="fp32", seed=5)
+  m.compile(SGD(0.05, momentum=0.9), "sparse_categorical_crossentropy")
+  # BatchNorm statistics are per replica in the reference (no SyncBN), so the equivalence
+  # with one big batch is exact only for the dense head of the first step; later layers see
+  # per-shard statistics.  Compare against a manual two-shard emulation instead.
+  from distributed_tensorflow_amd.engine.params import ParamStore
+  from distributed_tensorflow_amd.engine.torch_executor import TorchExecutor
+  spec = models.resnet20()
+  shards = [ParamStore(spec, "cpu", 5), ParamStore(spec, "cpu", 5)]
+  exs = [TorchExecutor(spec, s, 4) for s in shards]
+  vel = torch.zeros_like(shards[0].params)
+  for _ in range(3):
+    for r in range(2):
+      exs[r].train_step(X[r * 4:(r + 1) * 4], Y[r * 4:(r + 1) * 4].reshape(-1).long())
+    gsum = shards[0].grads + shards[1].grads
+    for s in shards:
+      gg = gsum / 2 + s.l2_vector() * s.params
+      v = 0.9 * vel - 0.05 * gg
+      s.params.add_(v)
+    vel = 0.9 * vel - 0.05 * (gsum / 2 + shards[0].l2_vector() * (shards[0].params - v))
+  ref = shards[0].view("fc10/kernel").flatten()[:16]
+  got = torch.tensor(res[0]["fc"])
+  assert torch.allclose(got, ref, rtol=1e-4, atol=1e-6)
+  ref_c = shards[0].view("conv1/kernel").flatten()[:16]
+  assert torch.allclose(torch.tensor(res[0]["conv1"]), ref_c, rtol=1e-3, atol=1e-6)
+
+
+def test_multi_worker_mirrored_from_tf_config(tmp_path):
+  """Rank and world size come from a TF_CONFIG cluster spec (two 'workers' on localhost)."""
+  sys.path.insert(0, ROOT)
+  from distributed_tensorflow_amd.launch import free_port
+  port = free_port()
+  script = tmp_path / "w.py"
+  script.write_text("import sys, os, json\nsys.path.insert(0, %r)\nimport torch\ntorch.set_num_threads(1)\n" % ROOT + textwrap.dedent("""
+    from distributed_tensorflow_amd import models
+    from distributed_tensorflow_amd.parallel import strategy as S, cluster
+    from distributed_tensorflow_amd.train.model import Model
+    from distributed_tensorflow_amd.train.optimizers import SGD
+    n = cluster.configure_cluster()
+    strat = S.get_distribution_strategy("multi_worker_mirrored", num_gpus=0, num_workers=n)
+    m = Model(models.resnet20(), strategy=strat, dtype="fp32", seed=strat.rank)
+    m.compile(SGD(0.1, momentum=0.9), "sparse_categorical_crossentropy")
+    g = torch.Generator().manual_seed(strat.rank)
+    x = torch.randn(2, 32, 32, 3, generator=g); y = torch.randint(0, 10, (2, 1), generator=g).float()
+    m.train_on_batch(x, y)
+    json.dump({"n": n, "rank": strat.rank, "world": strat.num_replicas_in_sync, "chief": strat.is_chief,
+               "psum": m.store.params.double().sum().item()},
+              open(os.path.join(os.environ["DTF_TEST_OUT"], "r%d.json" % strat.rank), "w"))
+    strat.barrier()
+  """))
+  procs = []
+  for idx in range(2):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+      env.pop(k, None)
+    env["TF_CONFIG"] = json.dumps({"cluster": {"worker": ["localhost:%d" % port, "localhost:%d" % (port + 1)]},
+                                   "task": {"type": "worker", "index": idx}})
+    env["DTF_TEST_OUT"] = str(tmp_path)
+    procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stderr=subprocess.PIPE))
+  errs = [p.communicate(timeout=300)[1].decode()[-2000:] for p in procs]
+  assert all(p.returncode == 0 for p in procs), errs
+  r = [json.load(open(tmp_path / ("r%d.json" % i))) for i in range(2)]
+  assert [x["rank"] for x in r] == [0, 1] and r[0]["world"] == 2 and r[0]["n"] == 2
+  assert r[0]["chief"] and not r[1]["chief"]
+  assert r[0]["psum"] == r[1]["psum"]
+
+
+def test_horovod_api(tmp_path):
+  body = COMMON + """
+from distributed_tensorflow_amd import hvd
+hvd.init(use_gpu=False)
+assert hvd.size() == world and hvd.rank() == rank and hvd.local_rank() == rank
+t = torch.full((4,), float(rank + 1))
+avg = hvd.allreduce(t); tot = hvd.allreduce(t, average=False)
+b = hvd.broadcast(torch.full((2,), float(rank + 7)), root_rank=1)
+m = Model(models.resnet20(), dtype="fp32", seed=rank)
+opt = hvd.DistributedOptimizer(SGD(0.1 * hvd.size(), momentum=0.9), fusion_threshold=1 << 20)
+m.compile(opt, "sparse_categorical_crossentropy", ["sparse_categorical_accuracy"])
+cbs = [hvd.callbacks.BroadcastGlobalVariablesCallback(0), hvd.callbacks.MetricAverageCallback(),
+       hvd.callbacks.LearningRateWarmupCallback(warmup_epochs=3, verbose=0)]
+class DS:
+  def __iter__(self):
+    while True:
+      yield X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+lrs = []
+from distributed_tensorflow_amd.train.callbacks import Callback
+class Rec(Callback):
+  def on_batch_begin(self, batch, logs=None):
+    lrs.append(self.model.optimizer.current_lr())
+h = m.fit(DS(), epochs=2, steps_per_epoch=2, callbacks=cbs + [Rec()], verbose=0)
+save({"avg": avg.tolist(), "tot": tot.tolist(), "b": b.tolist(), "psum": m.store.params.double().sum().item(),
+      "loss": [float(v) for v in h.history["loss"]], "lrs": lrs,
+      "buckets": len(m._bucket_list())})
+hvd.shutdown()
+"""
+  res = _run_ranks(tmp_path, body, 2)
+  assert res[0]["avg"] == [1.5] * 4 and res[0]["tot"] == [3.0] * 4
+  assert res[0]["b"] == [8.0, 8.0] and res[1]["b"] == [8.0, 8.0]
+  assert res[0]["psum"] == res[1]["psum"]                   # broadcast + averaged gradients
+  assert res[0]["loss"] == res[1]["loss"]                   # MetricAverageCallback
+  assert res[0]["buckets"] >= 2                              # 1 MB fusion threshold on 1.1 MB of grads
+  # warm-up: lr = lr0/size * (epoch*(size-1)/warmup + 1), epoch fractional (+ one step)
+  lr0, size, spe = 0.2, 2, 2
+  exp = [lr0 / size * (((e + (b + 1) / spe)) * (size - 1) / 3 + 1) for e in range(2) for b in range(spe)]
+  assert res[0]["lrs"] == pytest.approx(exp, rel=1e-6)
+
+
+def test_parameter_server_async(tmp_path):
+  """1 PS + 2 workers: pull -> compute -> push, PS applies SGD on arrival, clean shutdown."""
+  body = COMMON + """
+strat = S.get_distribution_strategy("parameter_server", num_gpus=0)
+m = Model(models.resnet20(), strategy=strat, dtype="fp32", seed=11)
+m.compile(SGD(0.05, momentum=0.9), "sparse_categorical_crossentropy", ["sparse_categorical_accuracy"])
+class DS:
+  def __iter__(self):
+    w = max(strat.worker_index, 0)
+    while True:
+      yield X[w * 4:(w + 1) * 4], Y[w * 4:(w + 1) * 4]
+p0 = m.store.params.clone()
+h = m.fit(DS(), epochs=1, steps_per_epoch=3, verbose=0)
+out = {"ps": strat.is_ps_task, "chief": strat.is_chief}
+if strat.is_ps_task:
+  out["updates"] = strat.updates_applied
+  out["moved"] = (m.store.params - p0).abs().sum().item()
+  out["mom"] = m.store.slot("momentum").abs().sum().item()
+  out["psum"] = m.store.params.double().sum().item()
+else:
+  ev = m.evaluate(DS(), steps=1)
+  out["loss"] = float(h.history["loss"][-1]); out["eval"] = [float(v) for v in ev]
+  out["psum"] = m.store.params.double().sum().item()
+  strat.shutdown()
+save(out)
+"""
+  res = _run_ranks(tmp_path, body, 3, num_ps=1)
+  assert res[0]["ps"] and not res[1]["ps"] and res[1]["chief"] and not res[2]["chief"]
+  assert res[0]["updates"] == 6                       # 2 workers x 3 pushes, none lost
+  assert res[0]["moved"] > 0 and res[0]["mom"] > 0
+  for r in res[1:]:
+    assert r["loss"] > 0 and len(r["eval"]) == 2
+  # a worker that pulls after everybody finished sees exactly the PS copy
+  assert any(abs(r["psum"] - res[0]["psum"]) < 1e-6 * abs(res[0]["psum"]) for r in res[1:])
+
+
+def test_launcher_fail_fast(tmp_path):
+  body = """
+import time
+rank = int(os.environ["RANK"])
+if rank == 1:
+  sys.exit(3)
+time.sleep(60)
+"""
+  script = tmp_path / "f.py"
+  script.write_text("import sys, os\n" + textwrap.dedent(body))
+  sys.path.insert(0, ROOT)
+  from distributed_tensorflow_amd import launch
+  import time
+  t0 = time.time()
+  code = launch.launch([str(script)], 2, log_dir=str(tmp_path / "logs"))
+  assert code == 3
+  assert time.time() - t0 < 30          # the surviving rank was torn down, not waited for
