@@ -48,6 +48,20 @@ def launch(argv: Sequence[str], nproc: int, num_ps: int = 0, master_addr: str = 
   logs = []
   if log_dir:
     os.makedirs(log_dir, exist_ok=True)
+
+  # The ranks run in their own sessions (so a rank's group can be signalled as a unit); a
+  # SIGTERM / SIGHUP to the launcher must therefore be forwarded or the ranks would outlive it.
+  def _on_signal(signum, _frame):
+    sys.stderr.write("[launch] got signal %d; stopping the job\n" % signum)
+    _kill_all(procs)
+    os._exit(128 + signum)
+
+  old_handlers = {}
+  for sig in (signal.SIGTERM, signal.SIGHUP):
+    try:
+      old_handlers[sig] = signal.signal(sig, _on_signal)
+    except ValueError:      # not in the main thread
+      pass
   try:
     for lr in range(nproc):
       rank = node_rank * nproc + lr
@@ -92,6 +106,8 @@ def launch(argv: Sequence[str], nproc: int, num_ps: int = 0, master_addr: str = 
     _kill_all(procs)
     return 130
   finally:
+    for sig, h in old_handlers.items():
+      signal.signal(sig, h)
     for f in logs:
       f.close()
 

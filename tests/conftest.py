@@ -16,7 +16,9 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
   """GPU tests are skipped when no GPU is visible (they are selected with -m gpu)."""
   import torch
-  if torch.cuda.is_available():
+  # device_count() does not initialise the GPU (is_available() would, and a process that has
+  # initialised the GPU must not start child programs on the test machines)
+  if torch.cuda.device_count() > 0:
     return
   skip = pytest.mark.skip(reason="needs a GPU")
   for item in items:

@@ -1,0 +1,52 @@
+"""Multi-rank run of the native executor on one GPU (runs first: it starts child processes,
+which has to happen before this pytest process initialises the GPU)."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(700)     # the first GPU start-up on a fresh machine can take minutes
+def test_two_ranks_native_executor_with_overlapped_allreduce(tmp_path):
+  """Two ranks share the one GPU of the test box (gloo backend): exercises the segmented
+  backward + bucket-ready path of the native executor under a real gradient reducer."""
+  import subprocess, textwrap, json
+  if torch.cuda.is_initialized():
+    pytest.skip("the GPU is already initialised in this process; child programs cannot be started")
+  script = tmp_path / "w.py"
+  script.write_text("import sys, os, json\nsys.path.insert(0, %r)\nimport torch\n" % ROOT + textwrap.dedent("""
+    from distributed_tensorflow_amd import models
+    from distributed_tensorflow_amd.parallel import strategy as S
+    from distributed_tensorflow_amd.train.model import Model
+    from distributed_tensorflow_amd.train.optimizers import SGD
+    strat = S.get_distribution_strategy("mirrored", num_gpus=1, num_packs=3)
+    rank = strat.rank
+    m = Model(models.resnet20(), strategy=strat, dtype="bf16", device=strat.device, seed=rank)
+    assert m.executor_kind == "hip"
+    m.compile(SGD(0.05, momentum=0.9), "sparse_categorical_crossentropy")
+    g = torch.Generator().manual_seed(rank)
+    x = (torch.randn(16, 32, 32, 3, generator=g) * 50 + 100).to(strat.device)
+    y = torch.randint(0, 10, (16, 1), generator=g).float().to(strat.device)
+    losses = [m.train_on_batch(x, y)[0].item() for _ in range(4)]
+    torch.cuda.synchronize()
+    json.dump({"psum": m.store.params.double().sum().item(), "losses": losses,
+               "ncoll": m._grad_reducer().collectives_launched},
+              open(os.path.join(os.environ["DTF_TEST_OUT"], "r%d.json" % rank), "w"))
+    strat.barrier()
+  """))
+  sys.path.insert(0, ROOT)
+  from distributed_tensorflow_amd import launch
+  code = launch.launch([str(script)], 2, log_dir=str(tmp_path / "logs"),
+                       env_extra={"DTF_TEST_OUT": str(tmp_path), "DTF_BACKEND": "gloo",
+                                  "LOCAL_RANK": "0"}, timeout_s=600)
+  logs = "".join((tmp_path / "logs" / ("log%d.log" % i)).read_text()[-2000:] for i in range(2))
+  assert code == 0, logs
+  r = [json.load(open(tmp_path / ("r%d.json" % i))) for i in range(2)]
+  assert r[0]["psum"] == pytest.approx(r[1]["psum"], rel=1e-9)
+  assert r[0]["ncoll"] == 4 * 3
+  assert r[0]["losses"][-1] < r[0]["losses"][0]
