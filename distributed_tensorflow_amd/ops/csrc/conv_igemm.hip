@@ -17,13 +17,15 @@
 // lane ends up holding 4*NR consecutive output channels of one pixel and stores
 // them with 16-byte writes, no LDS transpose in the epilogue.
 //
-// Pipeline: register-staged double buffering.  While the MFMAs of K-step t run
-// from LDS buffer t&1, the global loads of step t+1 are already in flight into
-// registers; they are written to the other LDS buffer after the math and one
-// barrier closes the step.  LDS rows are 64 bytes (32 bf16 of K); the four
-// 16-byte chunks of a row are XOR-swizzled so that the ds_read_b128 fragment
-// reads of a 16-lane group land on 16 distinct 16-byte slots of the 256-byte
-// bank row.
+// Pipeline: double-buffered direct-to-LDS loads (global_load_lds_dwordx4).  While
+// the MFMAs of K-step t run from LDS buffer t&1, the DMA of step t+1 fills the
+// other buffer; one barrier (with its vmcnt(0) wait) closes the step.  There is
+// no VGPR staging and no ds_write, whose 16-byte form moves only ~79 B/clk/CU and
+// made the register-staged version of this kernel LDS-bound.  LDS rows are 64
+// bytes (32 bf16 of K); the four 16-byte chunks of a row are XOR-swizzled so that
+// the ds_read_b128 fragment reads of a 16-lane group land on 16 distinct 16-byte
+// slots of the 256-byte bank row; with DMA writes the swizzle is applied to the
+// source address (LDS is filled linearly).
 //
 // Blocks are numbered so that the BN-tiles of one pixel tile share `blockIdx % 8`
 // (the label of the XCD they are dispatched to): they re-read the same input
@@ -38,8 +40,13 @@ namespace {
 
 constexpr int BK = 32;
 
+// 16 bytes of zeros in global memory: the source of every masked direct-to-LDS load.
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};
+
+// Second launch-bound argument = waves per SIMD the register allocation must allow: 4 blocks
+// of 4 waves per CU (64 accumulator registers + ~60 others fit the 128-register budget).
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool POINTWISE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, 4) void conv_igemm_kernel(const ConvParams p) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MR = WM / 16, NR = WN / 16;
   constexpr int XV = BM / 64;                       // 16-byte pixel-tile vectors per thread
@@ -66,9 +73,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int m0 = mt * BM, n0 = nt * BN;
 
   // ---- per-thread load geometry ----------------------------------------------------
-  const int kv = tid & 3;          // which 8-element (16-byte) piece of the 32-wide K step
-  const int lrow = tid >> 2;       // 0..63
-  int xbase[XV];                   // POINTWISE: element offset of the pixel row; else pixel index base n*H*W
+  // Tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging and no
+  // ds_write): one wave instruction fills 1 KiB = 16 tile rows of 64 bytes, lane l landing
+  // at row l/4, 16-byte slot l%4.  The XOR swizzle therefore moves to the *source*: the lane
+  // that owns physical slot s of a row fetches logical K-chunk s ^ g(row).  Out-of-image
+  // taps, rows past M and channels past Cout fetch from a 16-byte page of zeros.
+  const int lrow = tid >> 2;       // 0..63: tile row of this lane within a 64-row group
+  const int kvx = (tid & 3) ^ ((-(lrow >> 2)) & 3);            // logical K-chunk, pixel tile
+  const int kvw = (tid & 3) ^ ((-(lrow / (4 * NR))) & 3);      // logical K-chunk, weight tile
+  int xbase[XV];                   // POINTWISE: pixel row index; else pixel index base n*H*W
   int xh[XV], xw[XV];              // base input coordinates (before the tap offset)
 #pragma unroll
   for (int r = 0; r < XV; ++r) {
@@ -92,71 +105,59 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       }
     }
   }
-  // running decomposition of this thread's k index into (tap i, tap j, channel c)
-  int kc = kv * 8, ti = 0, tj = 0;
+  // running decomposition of the two k indices into (tap i, tap j, channel c)
+  int kkx = kvx * 8, kcx = kvx * 8, tix = 0, tjx = 0;
+  int kkw = kvw * 8, kcw = kvw * 8, tiw = 0, tjw = 0;
   if (!POINTWISE) {
-    while (kc >= p.Ctap) { kc -= p.Ctap; if (++tj == p.TJ) { tj = 0; ++ti; } }
+    while (kcx >= p.Ctap) { kcx -= p.Ctap; if (++tjx == p.TJ) { tjx = 0; ++tix; } }
+    while (kcw >= p.Ctap) { kcw -= p.Ctap; if (++tjw == p.TJ) { tjw = 0; ++tiw; } }
   }
-  int kk = kv * 8;                 // flat k of this thread's vector in the current step
 
   const bf16_t* __restrict__ gin = p.in;
   const bf16_t* __restrict__ gw = p.wgt;
+  const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_zero_page);
 
-  u32x4 xreg[XV], wreg[WV];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
 
-  auto load_tile = [&]() {
-    const bool kval = kk < p.Ktotal;
+  auto issue_tile = [&](int buf) {
+    uint8_t* xs = smem + buf * (XBYTES + WBYTES);
+    uint8_t* ws = xs + XBYTES;
+    const bool kvalx = kkx < p.Ktotal;
 #pragma unroll
     for (int r = 0; r < XV; ++r) {
+      const bf16_t* src;
       if (POINTWISE) {
-        const bool ok = kval && xbase[r] >= 0;
-        const size_t off = ok ? ((size_t)xbase[r] * p.Cpix + kk) : 0;
-        u32x4 v = *reinterpret_cast<const u32x4*>(gin + off);   // offset 0 is always readable
-        xreg[r] = ok ? v : zero4;
+        const bool ok = kvalx && xbase[r] >= 0;
+        src = ok ? gin + ((size_t)xbase[r] * p.Cpix + kkx) : zero_page;
       } else {
-        const int hi = xh[r] + ti * p.dhs;
-        const int wi = xw[r] + tj * p.dws;
-        const bool ok = kval && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        const size_t off = ok ? ((size_t)(xbase[r] + hi * p.W + wi) * p.Cpix + kc) : 0;
-        u32x4 v = *reinterpret_cast<const u32x4*>(gin + off);
-        xreg[r] = ok ? v : zero4;
+        const int hi = xh[r] + tix * p.dhs;
+        const int wi = xw[r] + tjx * p.dws;
+        const bool ok = kvalx && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        src = ok ? gin + ((size_t)(xbase[r] + hi * p.W + wi) * p.Cpix + kcx) : zero_page;
       }
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + r * 4096 + wave * 1024), 16, 0, 0);
     }
-    const int wk = POINTWISE ? (p.wk0 + kk) : (p.wk0 + ti * p.wsi + tj * p.wsj + kc);
+    const bool kvalw = kkw < p.Ktotal;
+    const int wk = POINTWISE ? (p.wk0 + kkw) : (p.wk0 + tiw * p.wsi + tjw * p.wsj + kcw);
 #pragma unroll
     for (int r = 0; r < WV; ++r) {
-      const int row = lrow + 64 * r;
-      const int co = n0 + row;
-      const bool ok = kval && row < BN && co < p.Cout;
-      const size_t off = ok ? ((size_t)co * p.ldw + wk) : 0;
-      u32x4 v = *reinterpret_cast<const u32x4*>(gw + off);
-      wreg[r] = ok ? v : zero4;
+      if (64 * r + wave * 16 < BN) {               // wave-uniform: whole 16-row pieces only
+        const int co = n0 + lrow + 64 * r;
+        const bool ok = kvalw && co < p.Cout;
+        const bf16_t* src = ok ? gw + ((size_t)co * p.ldw + wk) : zero_page;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ws + r * 4096 + wave * 1024), 16, 0, 0);
+      }
     }
   };
   auto advance_k = [&]() {
-    kk += BK;
+    kkx += BK;
+    kkw += BK;
     if (!POINTWISE) {
-      kc += BK;
-      while (kc >= p.Ctap) { kc -= p.Ctap; if (++tj == p.TJ) { tj = 0; ++ti; } }
-    }
-  };
-  auto store_tile = [&](int buf) {
-    uint8_t* xs = smem + buf * (XBYTES + WBYTES);
-    uint8_t* ws = xs + XBYTES;
-#pragma unroll
-    for (int r = 0; r < XV; ++r) {
-      const int row = lrow + 64 * r;
-      const int sw = (-(row >> 2)) & 3;
-      *reinterpret_cast<u32x4*>(xs + row * 64 + ((kv ^ sw) << 4)) = xreg[r];
-    }
-#pragma unroll
-    for (int r = 0; r < WV; ++r) {
-      const int row = lrow + 64 * r;
-      if (row < BN) {
-        const int sw = (-(row / (4 * NR))) & 3;
-        *reinterpret_cast<u32x4*>(ws + row * 64 + ((kv ^ sw) << 4)) = wreg[r];
-      }
+      kcx += BK;
+      while (kcx >= p.Ctap) { kcx -= p.Ctap; if (++tjx == p.TJ) { tjx = 0; ++tix; } }
+      kcw += BK;
+      while (kcw >= p.Ctap) { kcw -= p.Ctap; if (++tjw == p.TJ) { tjw = 0; ++tiw; } }
     }
   };
 
@@ -183,16 +184,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
   const int KT = (p.Ktotal + BK - 1) / BK;
   if (KT > 0) {
-    load_tile();
-    store_tile(0);
+    issue_tile(0);
     advance_k();
   }
-  __syncthreads();
+  __syncthreads();                                 // includes the vmcnt(0) wait for the DMA
 
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
     const bool more = kt + 1 < KT;
-    if (more) load_tile();                         // global loads in flight during the math
+    if (more) {                                    // next tile streams into the other buffer
+      issue_tile(buf ^ 1);                         // while this one is multiplied
+      advance_k();
+    }
     const uint8_t* xs = smem + buf * (XBYTES + WBYTES);
     const uint8_t* ws = xs + XBYTES;
     bf16x8 wf[NR], xf[MR];
@@ -205,10 +208,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
       for (int mr = 0; mr < MR; ++mr)
         acc[nr][mr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nr], xf[mr], acc[nr][mr], 0, 0, 0);
-    if (more) {
-      store_tile(buf ^ 1);
-      advance_k();
-    }
     __syncthreads();
   }
 

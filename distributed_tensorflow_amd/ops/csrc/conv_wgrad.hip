@@ -10,8 +10,8 @@
 //
 // Both MFMA operands need the *reduction* index (pixel) contiguous per lane, but both
 // tensors are pixel-major in memory (channels contiguous).  The tiles are therefore staged
-// in LDS as [32 pixels][channels] exactly as they arrive (16-byte global loads, 16-byte LDS
-// stores) and read back with ds_read_b64_tr_b16, gfx950's transposing LDS read: each lane
+// in LDS as [32 pixels][channels] exactly as they arrive (direct global->LDS DMA, double
+// buffered, no register staging) and read back with ds_read_b64_tr_b16, gfx950's transposing LDS read: each lane
 // gets 4 consecutive pixels of one channel per instruction, two reads form one 8-deep
 // MFMA operand.  The 32-byte column chunks of every LDS row are XOR-swizzled with a
 // function of the row so that the 8 rows touched by one 32-lane half fall into 8
@@ -25,6 +25,9 @@
 namespace {
 
 constexpr int BP = 32;  // pixels per reduction step
+
+// 16 bytes of zeros in global memory: the source of every masked direct-to-LDS load.
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page_w[4] = {0u, 0u, 0u, 0u};
 
 typedef __attribute__((address_space(3))) short4v lds_short4;
 
@@ -59,7 +62,7 @@ __device__ __forceinline__ bf16x8 read_tr_frag(const uint8_t* tile, int c0, int 
 }
 
 template <int BKK, int BCO, int WAVES_K, int WAVES_C, bool POINTWISE>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256, 4) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int WKK = BKK / WAVES_K, WCO = BCO / WAVES_C;
   constexpr int KR = WKK / 16, CR = WCO / 16;
   constexpr int XCPR = BKK / 8, YCPR = BCO / 8;                 // 16-byte chunks per tile row
@@ -81,8 +84,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const int pend = min(pbeg + p.pix_per_split, p.P);
   if (pbeg >= pend) return;
 
+  // Tiles go global -> LDS directly (global_load_lds_dwordx4): one wave instruction fills
+  // 1 KiB of the linear LDS image, lane l at byte 16*l.  The lane that owns physical 16-byte
+  // slot s of a row fetches the logical chunk that the XOR swizzle maps there, so the swizzle
+  // is applied to the source address; masked elements fetch from a page of zeros.
   // ---- X (input) gather geometry: this thread always loads the same 8 k-columns ----------
-  const int xch = tid % XCPR, xrow = tid / XCPR;
+  const int xrow = tid / XCPR, yrow = tid / YCPR;
+  auto unswizzle = [](int width, int row, int slot) {
+    if (width == 128) return ((((slot >> 1) ^ ((row & 3) | (((row >> 3) & 1) << 2))) << 1) | (slot & 1));
+    if (width == 64) return ((((slot >> 1) ^ (((row >> 1) & 1) | (((row >> 3) & 1) << 1))) << 1) | (slot & 1));
+    return slot;
+  };
+  const int xch = unswizzle(BKK, xrow, tid % XCPR);     // same for every row this lane fills
   const int kcol = k0 + xch * 8;
   const bool xk_ok = kcol < p.Ktotal;
   int kc = 0, ti = 0, tj = 0;
@@ -94,58 +107,49 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   }
   const int tap_h = p.dh0 + ti * p.dhs, tap_w = p.dw0 + tj * p.dws;
   // ---- dY geometry -------------------------------------------------------------------------
-  const int ych = tid % YCPR, yrow = tid / YCPR;
+  const int ych = unswizzle(BCO, yrow, tid % YCPR);
   const int ycol = c0 + ych * 8;
   const bool yc_ok = ycol < p.Cout;
 
   const bf16_t* __restrict__ gx = p.x;
   const bf16_t* __restrict__ gy = p.dy;
-  u32x4 xreg[XV], yreg[YV];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_zero_page_w);
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
 
-  auto load_tile = [&](int pstep) {
-#pragma unroll
-    for (int r = 0; r < XV; ++r) {
-      const int row = xrow + XRPP * r;
-      const int pp = pstep + row;
-      bool ok = xk_ok && row < BP && pp < pend;
-      size_t off = 0;
-      if (POINTWISE) {
-        off = ok ? ((size_t)pp * p.Cpix + kcol) : 0;
-      } else {
-        const uint32_t t = fd_div((uint32_t)(ok ? pp : 0), p.divOW);
-        const int ow = (ok ? pp : 0) - (int)t * p.OW;
-        const uint32_t n = fd_div(t, p.divOH);
-        const int oh = (int)t - (int)n * p.OH;
-        const int hi = oh * p.ISH + tap_h, wi = ow * p.ISW + tap_w;
-        ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        off = ok ? ((size_t)(((int)n * p.H + hi) * p.W + wi) * p.Cpix + kc) : 0;
-      }
-      const u32x4 v = *reinterpret_cast<const u32x4*>(gx + off);
-      xreg[r] = ok ? v : zero4;
-    }
-#pragma unroll
-    for (int r = 0; r < YV; ++r) {
-      const int row = yrow + YRPP * r;
-      const int pp = pstep + row;
-      const bool ok = yc_ok && row < BP && pp < pend;
-      const size_t off = ok ? ((size_t)pp * p.ldy + ycol) : 0;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(gy + off);
-      yreg[r] = ok ? v : zero4;
-    }
-  };
-  auto store_tile = [&](int buf) {
+  auto issue_tile = [&](int pstep, int buf) {
     uint8_t* xs = smem + buf * (XBYTES + YBYTES);
     uint8_t* ys = xs + XBYTES;
 #pragma unroll
     for (int r = 0; r < XV; ++r) {
-      const int row = xrow + XRPP * r;
-      if (row < BP) *reinterpret_cast<u32x4*>(xs + tile_off<BKK>(row, xch)) = xreg[r];
+      if (XRPP * r + wave * (64 / XCPR) < BP) {      // wave-uniform: whole 1 KiB pieces only
+        const int row = xrow + XRPP * r;
+        const int pp = pstep + row;
+        bool ok = xk_ok && pp < pend;
+        const bf16_t* src = zero_page;
+        if (POINTWISE) {
+          if (ok) src = gx + ((size_t)pp * p.Cpix + kcol);
+        } else {
+          const uint32_t t = fd_div((uint32_t)(ok ? pp : 0), p.divOW);
+          const int ow = (ok ? pp : 0) - (int)t * p.OW;
+          const uint32_t n = fd_div(t, p.divOH);
+          const int oh = (int)t - (int)n * p.OH;
+          const int hi = oh * p.ISH + tap_h, wi = ow * p.ISW + tap_w;
+          ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+          if (ok) src = gx + ((size_t)(((int)n * p.H + hi) * p.W + wi) * p.Cpix + kc);
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + r * 4096 + wave * 1024), 16, 0, 0);
+      }
     }
 #pragma unroll
     for (int r = 0; r < YV; ++r) {
-      const int row = yrow + YRPP * r;
-      if (row < BP) *reinterpret_cast<u32x4*>(ys + tile_off<BCO>(row, ych)) = yreg[r];
+      if (YRPP * r + wave * (64 / YCPR) < BP) {
+        const int row = yrow + YRPP * r;
+        const int pp = pstep + row;
+        const bool ok = yc_ok && pp < pend;
+        const bf16_t* src = ok ? gy + ((size_t)pp * p.ldy + ycol) : zero_page;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ys + r * 4096 + wave * 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -156,14 +160,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     for (int b = 0; b < CR; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nsteps = (pend - pbeg + BP - 1) / BP;
-  load_tile(pbeg);
-  store_tile(0);
-  __syncthreads();
+  issue_tile(pbeg, 0);
+  __syncthreads();                                  // includes the vmcnt(0) wait for the DMA
 
   for (int s = 0; s < nsteps; ++s) {
     const int buf = s & 1;
-    const bool more = s + 1 < nsteps;
-    if (more) load_tile(pbeg + (s + 1) * BP);
+    if (s + 1 < nsteps) issue_tile(pbeg + (s + 1) * BP, buf ^ 1);
     const uint8_t* xs = smem + buf * (XBYTES + YBYTES);
     const uint8_t* ys = xs + XBYTES;
     bf16x8 xf[KR], yf[CR];
@@ -176,7 +178,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int b = 0; b < CR; ++b)
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], yf[b], acc[a][b], 0, 0, 0);
-    if (more) store_tile(buf ^ 1);
     __syncthreads();
   }
 
