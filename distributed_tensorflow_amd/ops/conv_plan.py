@@ -50,8 +50,10 @@ def pick_fwd_cfg(M: int, cout: int) -> int:
   return 0
 
 
-def pick_wgrad_cfg(ktotal: int, cout: int, P: int, target_blocks: int = 768) -> Tuple[int, int]:
+def pick_wgrad_cfg(ktotal: int, cout: int, P: int, target_blocks: int = 0) -> Tuple[int, int]:
   """(cfg, splits) for the weight gradient."""
+  import os  # pylint: disable=import-outside-toplevel
+  target_blocks = target_blocks or int(os.environ.get("DTF_WGRAD_TARGET_BLOCKS", "768"))
   if cout <= 16:
     bco = 16
   elif cout <= 32:
