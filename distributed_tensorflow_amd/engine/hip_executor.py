@@ -57,9 +57,11 @@ def supports(spec: ModelSpec) -> bool:
 
 class HipExecutor:
   native = True
+  STATS_REPLICAS = 32     # rows of atomically accumulated BatchNorm sums per layer
 
   def __init__(self, spec: ModelSpec, store: ParamStore, batch_size: int, dtype: str = "bf16",
-               buckets: Optional[List[Bucket]] = None, use_graph: Optional[bool] = None):
+               buckets: Optional[List[Bucket]] = None, use_graph: Optional[bool] = None,
+               fused_bn_stats: Optional[bool] = None):
     if store.device.type != "cuda":
       raise RuntimeError("HipExecutor needs a GPU device")
     if dtype not in ("bf16", "bfloat16"):
@@ -75,6 +77,12 @@ class HipExecutor:
     if use_graph is None:
       use_graph = os.environ.get("DTF_HIP_GRAPH", "1") != "0"
     self.use_graph = use_graph
+    # BatchNorm statistics accumulated in the convolution epilogue with float atomics (one
+    # sweep over the activations less, summation order not fixed) or by the separate
+    # deterministic sweep
+    if fused_bn_stats is None:
+      fused_bn_stats = os.environ.get("DTF_FUSED_BN_STATS", "1") != "0"
+    self.fused_bn_stats = fused_bn_stats
     self._keep: List[torch.Tensor] = []      # owns every planned buffer
     self._graph_stream: Optional[torch.cuda.Stream] = None
     self._train_graph = None
@@ -165,6 +173,26 @@ class HipExecutor:
       bn_off[b.name] = o
       o += 4 * b.attrs["channels"]
     self._bn_off = bn_off
+    # fused statistics: replicas of [2][C] sums per BatchNorm whose input comes straight from
+    # a convolution; ReLU bit masks ([P][C/8] bytes) for the backward sweeps
+    producer = {o.output: o for o in spec.ops}
+    self._bn_stats_off: Dict[str, int] = {}
+    self._bn_mask: Dict[str, torch.Tensor] = {}
+    so = 0
+    for b in bn_ops:
+      src = producer.get(b.inputs[0])
+      c = b.attrs["channels"]
+      if (self.fused_bn_stats and src is not None and src.kind == "conv"
+          and consumers.get(b.inputs[0], 0) == 1 and c % 8 == 0
+          and acts[b.inputs[0]].shape[-1] == c):
+        self._bn_stats_off[b.name] = so
+        so += self.STATS_REPLICAS * 2 * c
+      if b.attrs["relu"]:
+        self._bn_mask[b.name] = self._alloc((acts[b.output].numel() // 8,), torch.uint8,
+                                            zero=False)
+    self.bn_stats = self._alloc((max(so, 1),), torch.float32)
+    self._stats_of_conv = {b.inputs[0]: self.bn_stats.data_ptr() + 4 * self._bn_stats_off[b.name]
+                           for b in bn_ops if b.name in self._bn_stats_off}
 
     ext = native.ext()
     self.fwd_plan = ext.Plan()
@@ -227,13 +255,17 @@ class HipExecutor:
     acts = self.acts
     plan.add("memset", dict(ptr=self.accum.data_ptr(), nbytes=8), "zero_loss")
     plan.add("preprocess_pad", self._pre, "preprocess")
+    if training and self._bn_stats_off:
+      plan.add("memset", dict(ptr=self.bn_stats.data_ptr(), nbytes=self.bn_stats.numel() * 4),
+               "zero_bn_stats")
     for op in spec.ops:
       at = op.attrs
       x = acts[op.inputs[0]]
       if op.kind == "conv":
         g = self.geoms[op.name]
-        plan.add("conv", g.fwd(x.data_ptr(), self._wf_ptr(op.name), acts[op.output].data_ptr()),
-                 op.name)
+        st = self._stats_of_conv.get(op.output) if training else None
+        plan.add("conv", g.fwd(x.data_ptr(), self._wf_ptr(op.name), acts[op.output].data_ptr(),
+                               stats=st, stats_replicas=self.STATS_REPLICAS), op.name)
       elif op.kind == "dense":
         g = self.geoms[op.name]
         plan.add("conv", g.fwd(x.data_ptr(), self._wf_ptr(op.name), acts[op.output].data_ptr(),
@@ -251,10 +283,14 @@ class HipExecutor:
                       mv=self._var_ptr(op.name + "/moving_variance"),
                       P=P, C=C, eps=float(at["eps"]), relu=int(at["relu"]))
         if training:
+          fused = op.name in self._bn_stats_off
+          ws = (self.bn_stats.data_ptr() + 4 * self._bn_stats_off[op.name]) if fused \
+              else self.bn_ws.data_ptr()
+          mask = self._bn_mask[op.name].data_ptr() if op.name in self._bn_mask else None
           plan.add("bn_fwd_train", dict(
               save_mean=mean_p, save_invstd=mean_p + 4 * C, scale=mean_p + 8 * C,
-              shift=mean_p + 12 * C, ws=self.bn_ws.data_ptr(), momentum=float(at["momentum"]),
-              **common), op.name)
+              shift=mean_p + 12 * C, ws=ws, fused_replicas=self.STATS_REPLICAS if fused else 0,
+              mask=mask, momentum=float(at["momentum"]), **common), op.name)
         else:
           plan.add("bn_infer", common, op.name)
       elif op.kind == "maxpool":
@@ -374,7 +410,8 @@ class HipExecutor:
           written.add(rname)
         plan.add("bn_bwd", dict(
             dz=dout.data_ptr(), y=x.data_ptr(),
-            z=acts[op.output].data_ptr() if at["relu"] else None, mean=mean_p, invstd=inv_p,
+            z=None, mask=self._bn_mask[op.name].data_ptr() if at["relu"] else None,
+            mean=mean_p, invstd=inv_p,
             gamma=self._var_ptr(op.name + "/gamma"),
             dgamma=self._var_ptr(op.name + "/gamma", "grad"),
             dbeta=self._var_ptr(op.name + "/beta", "grad"), dy=dy.data_ptr(), dres=dres,

@@ -141,7 +141,10 @@ class ConvGeom:
 
   # -- forward ----------------------------------------------------------------------------
   def fwd(self, x: int, w: int, out: int, bias: Optional[int] = None,
-          cfg: Optional[int] = None) -> Dict:
+          cfg: Optional[int] = None, stats: Optional[int] = None,
+          stats_replicas: int = 0) -> Dict:
+    """`stats`: fp32 [stats_replicas][2][Cout] buffer (zeroed by the caller) that receives the
+    per-channel sum / sum of squares of the output for a following BatchNorm."""
     pt, _, pl, _ = self.pad
     d = dict(N=self.N, H=self.Hs, W=self.Ws, Cpix=self.Cs, OH=self.OH, OW=self.OW,
              Cout=self.Cout, ldc=self.ldc, ISH=self.stride, ISW=self.stride, dhs=1, dws=1,
@@ -150,6 +153,9 @@ class ConvGeom:
     d["wgt"] = w
     d["out"] = out
     d["bias"] = bias
+    if stats is not None:
+      d["stats"] = stats
+      d["stats_replicas"] = stats_replicas
     if self.mode == "merged":
       d.update(TI=self.KH, TJ=1, Ctap=32, dh0=0, dw0=0, wsi=32, wsj=32)
     else:

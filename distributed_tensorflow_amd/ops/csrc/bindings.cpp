@@ -53,6 +53,8 @@ ConvParams conv_from_dict(const py::dict& d) {
   p.out = ptr<bf16_t>(d, "out");
   p.addend = ptr<const bf16_t>(d, "addend", false);
   p.bias = ptr<const float>(d, "bias", false);
+  p.stats = ptr<float>(d, "stats", false);
+  p.stats_replicas = get_or<int>(d, "stats_replicas", 0);
   p.N = get<int>(d, "N"); p.H = get<int>(d, "H"); p.W = get<int>(d, "W");
   p.Cpix = get<int>(d, "Cpix");
   p.OH = get<int>(d, "OH"); p.OW = get<int>(d, "OW");
@@ -128,12 +130,15 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     auto smean = ptr<float>(d, "save_mean"); auto sinv = ptr<float>(d, "save_invstd");
     auto scale = ptr<float>(d, "scale"); auto shift = ptr<float>(d, "shift");
     auto ws = ptr<float>(d, "ws");
+    auto mask = ptr<uint8_t>(d, "mask", false);
+    // > 0: the producing convolution left that many replicas of [2][C] sums in `ws`
+    const int fused = get_or<int>(d, "fused_replicas", 0);
     const int P = get<int>(d, "P"), C = get<int>(d, "C");
     const float eps = get<float>(d, "eps"), mom = get<float>(d, "momentum");
     const int relu = get<int>(d, "relu");
     return [=](hipStream_t s) {
-      launch_bn_fwd_train(y, res, z, gamma, beta, mm, mv, smean, sinv, scale, shift, ws, P, C,
-                          eps, mom, relu, s);
+      launch_bn_fwd_train(y, res, z, mask, gamma, beta, mm, mv, smean, sinv, scale, shift, ws,
+                          fused, P, C, eps, mom, relu, s);
     };
   }
   if (kind == "bn_infer") {
@@ -149,6 +154,7 @@ Launch make_op(const std::string& kind, const py::dict& d) {
   if (kind == "bn_bwd") {
     auto dz = ptr<const bf16_t>(d, "dz"); auto y = ptr<const bf16_t>(d, "y");
     auto z = ptr<const bf16_t>(d, "z", false);
+    auto mask = ptr<const uint8_t>(d, "mask", false);
     auto mean = ptr<const float>(d, "mean"); auto inv = ptr<const float>(d, "invstd");
     auto gamma = ptr<const float>(d, "gamma");
     auto dgamma = ptr<float>(d, "dgamma"); auto dbeta = ptr<float>(d, "dbeta");
@@ -156,7 +162,7 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     auto ws = ptr<float>(d, "ws");
     const int P = get<int>(d, "P"), C = get<int>(d, "C");
     return [=](hipStream_t s) {
-      launch_bn_bwd(dz, y, z, mean, inv, gamma, dgamma, dbeta, dy, dres, ws, P, C, s);
+      launch_bn_bwd(dz, y, z, mask, mean, inv, gamma, dgamma, dbeta, dy, dres, ws, P, C, s);
     };
   }
   if (kind == "maxpool_fwd" || kind == "maxpool_bwd") {

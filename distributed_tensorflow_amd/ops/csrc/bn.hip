@@ -17,6 +17,12 @@
 // which also emits g itself as the gradient of the residual branch when asked.  The sums are
 // deterministic (fixed partition, fixed order).
 //
+// Two traffic savers: the forward sweep can leave the ReLU mask as one bit per element
+// (`mask`, a byte per 8 channels) so that both backward sweeps read 1/16 of what re-reading
+// the bf16 output would cost; and the statistics sweep disappears when the producing
+// convolution already accumulated sum / sum of squares in its epilogue (`fused_stats`: the
+// workspace then holds `G` replicas filled with atomic adds).
+//
 // All kernels are bandwidth bound: every thread moves 16 bytes (8 channels) per access, a row
 // of C channels is covered by C/8 consecutive lanes, and a block walks rows grid-strided.
 #include <stdexcept>
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(TPB) void bn_fwd_finalize_kernel(const BnFinalizeAr
 }
 
 struct BnApplyArgs {
-  const bf16_t* y; const bf16_t* res; bf16_t* z;
+  const bf16_t* y; const bf16_t* res; bf16_t* z; uint8_t* mask;
   const float* scale; const float* shift;        // training: produced by the finalize kernel
   const float* gamma; const float* beta; const float* mm; const float* mv;   // inference
   int P, C; float eps; int relu;
@@ -194,6 +200,12 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
       for (int c = 0; c < 8; ++c) f[c] += r[c];
     }
     if (a.relu) {
+      if (a.mask) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bits |= (f[c] > 0.f ? 1u : 0u) << c;
+        a.mask[(size_t)row * tpr + chunk] = (uint8_t)bits;
+      }
 #pragma unroll
       for (int c = 0; c < 8; ++c) f[c] = fmaxf(f[c], 0.f);
     }
@@ -202,7 +214,9 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
 }
 
 struct BnBwdArgs {
-  const bf16_t* dz; const bf16_t* y; const bf16_t* z;   // z == nullptr: no ReLU mask
+  const bf16_t* dz; const bf16_t* y;
+  const bf16_t* z;          // forward output: ReLU mask = z > 0 (used when `mask` is null)
+  const uint8_t* mask;      // bit mask written by the forward sweep; both null: no ReLU
   const float* mean; const float* invstd; const float* gamma;
   float* dgamma; float* dbeta;
   bf16_t* dy; bf16_t* dres;
@@ -227,7 +241,11 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
     float g[8], yv[8];
     unpack8(*reinterpret_cast<const u32x4*>(a.dz + off), g);
     unpack8(*reinterpret_cast<const u32x4*>(a.y + off), yv);
-    if (a.z) {
+    if (a.mask) {
+      const uint32_t bits = a.mask[(size_t)row * tpr + chunk];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) g[c] = (bits >> c) & 1u ? g[c] : 0.f;
+    } else if (a.z) {
       float zv[8];
       unpack8(*reinterpret_cast<const u32x4*>(a.z + off), zv);
 #pragma unroll
@@ -272,7 +290,11 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
     float g[8], yv[8];
     unpack8(*reinterpret_cast<const u32x4*>(a.dz + off), g);
     unpack8(*reinterpret_cast<const u32x4*>(a.y + off), yv);
-    if (a.z) {
+    if (a.mask) {
+      const uint32_t bits = a.mask[(size_t)row * tpr + chunk];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) g[c] = (bits >> c) & 1u ? g[c] : 0.f;
+    } else if (a.z) {
       float zv[8];
       unpack8(*reinterpret_cast<const u32x4*>(a.z + off), zv);
 #pragma unroll
@@ -314,17 +336,21 @@ int reduce_grid(int P, int C) {
 
 size_t bn_workspace_floats() { return (size_t)MAX_PARTIAL_BLOCKS * 2 * 2048; }
 
-void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, const float* gamma,
-                         const float* beta, float* mm, float* mv, float* save_mean,
-                         float* save_invstd, float* scale, float* shift, float* ws, int P, int C,
-                         float eps, float momentum, int relu, hipStream_t s) {
+void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, uint8_t* mask,
+                         const float* gamma, const float* beta, float* mm, float* mv,
+                         float* save_mean, float* save_invstd, float* scale, float* shift,
+                         float* ws, int fused_replicas, int P, int C, float eps, float momentum,
+                         int relu, hipStream_t s) {
   check_channels(C, P);
-  const int G = reduce_grid(P, C);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(G), dim3(TPB), 0, s, y, ws, P, C);
+  int G = fused_replicas;             // > 0: `ws` already holds that many rows of [2][C] sums
+  if (G <= 0) {
+    G = reduce_grid(P, C);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(G), dim3(TPB), 0, s, y, ws, P, C);
+  }
   BnFinalizeArgs f{ws, G, gamma, beta, mm, mv, save_mean, save_invstd, scale, shift,
                    P, C, eps, momentum};
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 31) / 32), dim3(TPB), 0, s, f);
-  BnApplyArgs a{y, res, z, scale, shift, gamma, beta, mm, mv, P, C, eps, relu};
+  BnApplyArgs a{y, res, z, mask, scale, shift, gamma, beta, mm, mv, P, C, eps, relu};
   hipLaunchKernelGGL(bn_apply_kernel, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
 }
 
@@ -332,16 +358,17 @@ void launch_bn_infer(const bf16_t* y, const bf16_t* res, bf16_t* z, const float*
                      const float* beta, const float* mm, const float* mv, int P, int C, float eps,
                      int relu, hipStream_t s) {
   check_channels(C, P);
-  BnApplyArgs a{y, res, z, nullptr, nullptr, gamma, beta, mm, mv, P, C, eps, relu};
+  BnApplyArgs a{y, res, z, nullptr, nullptr, nullptr, gamma, beta, mm, mv, P, C, eps, relu};
   hipLaunchKernelGGL(bn_apply_kernel, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
 }
 
-void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const float* mean,
-                   const float* invstd, const float* gamma, float* dgamma, float* dbeta,
-                   bf16_t* dy, bf16_t* dres, float* ws, int P, int C, hipStream_t s) {
+void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const uint8_t* mask,
+                   const float* mean, const float* invstd, const float* gamma, float* dgamma,
+                   float* dbeta, bf16_t* dy, bf16_t* dres, float* ws, int P, int C,
+                   hipStream_t s) {
   check_channels(C, P);
   const int G = reduce_grid(P, C);
-  BnBwdArgs a{dz, y, z, mean, invstd, gamma, dgamma, dbeta, dy, dres, ws, G, P, C};
+  BnBwdArgs a{dz, y, z, mask, mean, invstd, gamma, dgamma, dbeta, dy, dres, ws, G, P, C};
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(G), dim3(TPB), 0, s, a);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(TPB), 0, s, a);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);

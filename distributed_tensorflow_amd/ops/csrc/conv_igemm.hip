@@ -45,6 +45,32 @@ __device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0
 
 // Second launch-bound argument = waves per SIMD the register allocation must allow: 4 blocks
 // of 4 waves per CU (64 accumulator registers + ~60 others fit the 128-register budget).
+// Sum over the 16 lanes that share lane/16 (the 16 pixels of an MFMA column block), leaving
+// the totals scattered over those lanes: a halving butterfly - at step T a lane keeps one
+// half of its values and hands the other half to lane ^ (1 << T) - so NV values cost NV - 1
+// shuffles in total instead of 4 * NV.  Afterwards v[0 .. (NV >> steps) - 1] of a lane hold the
+// totals of the original indices  base + j,  base = sum_T bit_T(lane) * (NV >> (T + 1)).
+template <int NV, int N, int T>
+__device__ __forceinline__ void butterfly16(float (&v)[NV], int fr) {
+  if constexpr (T < 4) {
+    if constexpr (N > 1) {
+      constexpr int H = N / 2;
+      const bool up = (fr >> T) & 1;
+#pragma unroll
+      for (int i = 0; i < H; ++i) {
+        const float send = up ? v[i] : v[i + H];
+        const float keep = up ? v[i + H] : v[i];
+        v[i] = keep + __shfl_xor(send, 1 << T);
+      }
+      butterfly16<NV, H, T + 1>(v, fr);
+    } else {
+      v[0] += __shfl_xor(v[0], 1 << T);
+      butterfly16<NV, 1, T + 1>(v, fr);
+    }
+  }
+}
+
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool POINTWISE>
 __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(const ConvParams p) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -219,6 +245,11 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(const ConvParams p) 
   for (int c = 0; c < CPL; ++c)
     bias[c] = (p.bias != nullptr && co0 + c < p.Cout) ? p.bias[co0 + c] : 0.f;
   const bool vec_ok = (p.ldc % 8 == 0);
+  // fused batch-norm statistics: [0, CPL) sums, [CPL, 2*CPL) sums of squares of this lane's
+  // channels over its MR pixels (the host guarantees the vector store path in that case)
+  float st[2 * CPL];
+#pragma unroll
+  for (int c = 0; c < 2 * CPL; ++c) st[c] = 0.f;
 #pragma unroll
   for (int mr = 0; mr < MR; ++mr) {
     const int m = m0 + wm * WM + mr * 16 + fr;
@@ -255,6 +286,17 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(const ConvParams p) 
           u32x4 o;
           o.x = pack2bf(v0, v1); o.y = pack2bf(v2, v3); o.z = pack2bf(v4, v5); o.w = pack2bf(v6, v7);
           *reinterpret_cast<u32x4*>(optr + h * 8) = o;
+          if (p.stats) {
+            const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+              st[h * 8 + 2 * j] += lo;
+              st[h * 8 + 2 * j + 1] += hi;
+              st[CPL + h * 8 + 2 * j] += lo * lo;
+              st[CPL + h * 8 + 2 * j + 1] += hi * hi;
+            }
+          }
         } else {
           const float vv[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
 #pragma unroll
@@ -281,6 +323,17 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(const ConvParams p) 
         o.x = pack2bf(v0, v1);
         o.y = pack2bf(v2, v3);
         *reinterpret_cast<u32x2*>(optr) = o;
+        if (p.stats) {
+          const uint32_t w[2] = {o.x, o.y};
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+            st[2 * j] += lo;
+            st[2 * j + 1] += hi;
+            st[CPL + 2 * j] += lo * lo;
+            st[CPL + 2 * j + 1] += hi * hi;
+          }
+        }
       } else {
         const float vv[4] = {v0, v1, v2, v3};
 #pragma unroll
@@ -291,6 +344,24 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(const ConvParams p) 
             optr[c] = f2bf(x);
           }
         }
+      }
+    }
+  }
+  if (p.stats) {
+    constexpr int NV = 2 * CPL;
+    constexpr int HALVINGS = NV >= 16 ? 4 : 3;     // NV is 8, 16 or 32
+    constexpr int LEFT = NV >> HALVINGS;           // totals per lane afterwards
+    butterfly16<NV, NV, 0>(st, fr);
+    int base = 0;
+#pragma unroll
+    for (int t = 0; t < HALVINGS; ++t) base += ((fr >> t) & 1) * (NV >> (t + 1));
+    if (HALVINGS == 4 || (fr >> 3) == 0) {
+      float* dst = p.stats + (size_t)(mt % p.stats_replicas) * 2 * p.Cout;
+#pragma unroll
+      for (int j = 0; j < LEFT; ++j) {
+        const int idx = base + j;
+        const int q = idx / CPL, c = idx % CPL;    // quantity (sum / sum of squares), channel
+        if (co0 + c < p.Cout) atomicAdd(dst + q * p.Cout + co0 + c, st[j]);
       }
     }
   }
@@ -329,6 +400,11 @@ void validate_conv_params(const ConvParams& p) {
   if (p.TI * p.TJ > 0 && p.wk0 + (p.TI - 1) * p.wsi + (p.TJ - 1) * p.wsj + p.Ctap > p.ldw)
     fail("weight row overrun");
   if (p.Cout <= 0 || p.ldc < p.Cout) fail("ldc < Cout");
+  if (p.stats) {
+    if (p.stats_replicas <= 0) fail("stats needs a positive replica count");
+    if (p.bias || p.addend) fail("fused statistics need a plain convolution (no bias / addend)");
+    if (p.Cout % 8 || p.ldc % 8) fail("fused statistics need Cout and ldc to be multiples of 8");
+  }
   if ((p.OH - 1) * p.OSH + p.OOH >= p.OHfull || (p.OW - 1) * p.OSW + p.OOW >= p.OWfull)
     fail("output index overrun");
   // every in-bounds pixel read must stay inside the input tensor: pixel*Cpix + Ctap <= total

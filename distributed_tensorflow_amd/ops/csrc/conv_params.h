@@ -10,6 +10,11 @@ struct ConvParams {
   bf16_t* out = nullptr;           // [N, OHfull, OWfull, ldc]
   const bf16_t* addend = nullptr;  // optional tensor added to the result (same layout as out)
   const float* bias = nullptr;     // optional per-output-channel bias
+  // optional fused batch-norm statistics: per-channel sum / sum of squares of the (bf16
+  // rounded) output, added atomically into replica (m-tile % replicas) of
+  // stats[replicas][2][Cout]; the buffer is zeroed by the caller
+  float* stats = nullptr;
+  int stats_replicas = 0;
   int N = 0, H = 0, W = 0, Cpix = 0;
   int OH = 0, OW = 0, M = 0;       // logical output grid; M = N*OH*OW
   int OHfull = 0, OWfull = 0, ldc = 0;

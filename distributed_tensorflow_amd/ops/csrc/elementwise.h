@@ -3,16 +3,20 @@
 #include "common.h"
 
 size_t bn_workspace_floats();
-void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, const float* gamma,
-                         const float* beta, float* mm, float* mv, float* save_mean,
-                         float* save_invstd, float* scale, float* shift, float* ws, int P, int C,
-                         float eps, float momentum, int relu, hipStream_t s);
+// `mask` (optional): one bit per element of the ReLU mask, [P][C/8] bytes.
+// `fused_replicas` > 0: `ws` holds that many rows of [2][C] sums left by the convolution.
+void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, uint8_t* mask,
+                         const float* gamma, const float* beta, float* mm, float* mv,
+                         float* save_mean, float* save_invstd, float* scale, float* shift,
+                         float* ws, int fused_replicas, int P, int C, float eps, float momentum,
+                         int relu, hipStream_t s);
 void launch_bn_infer(const bf16_t* y, const bf16_t* res, bf16_t* z, const float* gamma,
                      const float* beta, const float* mm, const float* mv, int P, int C, float eps,
                      int relu, hipStream_t s);
-void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const float* mean,
-                   const float* invstd, const float* gamma, float* dgamma, float* dbeta,
-                   bf16_t* dy, bf16_t* dres, float* ws, int P, int C, hipStream_t s);
+void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const uint8_t* mask,
+                   const float* mean, const float* invstd, const float* gamma, float* dgamma,
+                   float* dbeta, bf16_t* dy, bf16_t* dres, float* ws, int P, int C,
+                   hipStream_t s);
 
 void launch_maxpool_fwd(const bf16_t* x, bf16_t* out, uint8_t* idx, int N, int H, int W, int C,
                         int OH, int OW, int k, int stride, int pt, int pl, hipStream_t s);

@@ -101,6 +101,52 @@ def test_conv_fwd_dgrad_wgrad(case):
   assert err <= 0.01 * wr.grad.abs().max().item() + 1e-2, err
 
 
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, K, Cout, stride, cfg
+    (4, 28, 28, 64, 3, 128, 1, 0), (4, 28, 28, 64, 1, 64, 1, 1), (3, 17, 17, 16, 3, 32, 1, 2),
+    (3, 17, 17, 16, 3, 16, 2, 3), (2, 14, 14, 256, 1, 512, 1, 4), (4, 28, 28, 128, 1, 64, 1, 5),
+    (2, 9, 9, 32, 3, 72, 1, 0)])
+def test_conv_fused_bn_statistics(case):
+  """The epilogue's per-channel sum / sum of squares equal those of the stored bf16 output,
+  followed by the BatchNorm finalize that consumes the replicas."""
+  native = _native()
+  N, H, W, Cin, K, Cout, stride, cfg = case
+  dev = torch.device("cuda")
+  gen = torch.Generator(device="cpu").manual_seed(sum(case))
+  pad = same_padding(H, K, stride) + same_padding(W, K, stride)
+  g = ConvGeom(N, H, W, Cin, K, K, Cout, stride, pad)
+  x = _bf(torch.randn(N, H, W, Cin, generator=gen) + 0.3).to(dev)
+  w = (torch.randn(K, K, Cin, Cout, generator=gen) * (1.0 / math.sqrt(K * K * Cin))).to(dev)
+  wf = _pack(native, g, w, "fwd")
+  R = 5
+  out = torch.zeros(g.output_shape, dtype=torch.bfloat16, device=dev)
+  stats = torch.zeros(R, 2, Cout, device=dev)
+  native.run_op("conv", g.fwd(x.data_ptr(), wf.data_ptr(), out.data_ptr(), cfg=cfg,
+                              stats=stats.data_ptr(), stats_replicas=R))
+  torch.cuda.synchronize()
+  o = out.float().reshape(-1, g.ldc)[:, :Cout]
+  tot = stats.sum(0)
+  assert torch.allclose(tot[0], o.sum(0), rtol=1e-3, atol=1e-2)
+  assert torch.allclose(tot[1], (o * o).sum(0), rtol=1e-3, atol=1e-2)
+  if Cout & (Cout - 1) == 0:
+    P = o.shape[0]
+    gamma = torch.ones(Cout, device=dev)
+    beta = torch.zeros(Cout, device=dev)
+    mm = torch.zeros(Cout, device=dev)
+    mv = torch.ones(Cout, device=dev)
+    saved = torch.zeros(4 * Cout, device=dev)
+    z = torch.empty(P, Cout, dtype=torch.bfloat16, device=dev)
+    native.run_op("bn_fwd_train", dict(
+        y=out.data_ptr(), res=None, z=z.data_ptr(), gamma=gamma.data_ptr(), beta=beta.data_ptr(),
+        mm=mm.data_ptr(), mv=mv.data_ptr(), save_mean=saved.data_ptr(),
+        save_invstd=saved.data_ptr() + 4 * Cout, scale=saved.data_ptr() + 8 * Cout,
+        shift=saved.data_ptr() + 12 * Cout, ws=stats.data_ptr(), fused_replicas=R, P=P, C=Cout,
+        eps=1e-5, momentum=0.9, relu=0))
+    torch.cuda.synchronize()
+    ref = (o - o.mean(0)) * torch.rsqrt(o.var(0, unbiased=False) + 1e-5)
+    assert torch.allclose(z.float(), ref, rtol=2e-2, atol=2e-2)
+
+
 def test_conv_mfma_layout_identity():
   """A = I with an asymmetric B: catches a transposed / permuted accumulator mapping."""
   native = _native()
@@ -173,9 +219,10 @@ def test_stem_merged_taps_and_dense():
   assert (dwd - ref_dw).abs().max().item() <= 0.01 * ref_dw.abs().max().item() + 1e-2
 
 
-@pytest.mark.parametrize("C,relu,residual", [(64, True, False), (256, True, True),
-                                             (16, False, False), (2048, True, True)])
-def test_batchnorm_fwd_bwd(C, relu, residual):
+@pytest.mark.parametrize("C,relu,residual,use_mask", [
+    (64, True, False, False), (256, True, True, True), (16, False, False, False),
+    (2048, True, True, False), (8, True, False, True), (512, True, False, True)])
+def test_batchnorm_fwd_bwd(C, relu, residual, use_mask):
   native = _native()
   dev = torch.device("cuda")
   gen = torch.Generator().manual_seed(C)
@@ -189,8 +236,10 @@ def test_batchnorm_fwd_bwd(C, relu, residual):
   saved = torch.zeros(4 * C, device=dev)
   ws = torch.zeros(native.ext().bn_workspace_floats(), device=dev)
   z = torch.empty(P, C, dtype=torch.bfloat16, device=dev)
+  mask = torch.full((P * C // 8,), 0xAA, dtype=torch.uint8, device=dev) if use_mask else None
   native.run_op("bn_fwd_train", dict(
       y=y.data_ptr(), res=res.data_ptr() if residual else None, z=z.data_ptr(),
+      mask=mask.data_ptr() if use_mask else None,
       gamma=gamma.data_ptr(), beta=beta.data_ptr(), mm=mm.data_ptr(), mv=mv.data_ptr(),
       save_mean=saved.data_ptr(), save_invstd=saved.data_ptr() + 4 * C,
       scale=saved.data_ptr() + 8 * C, shift=saved.data_ptr() + 12 * C, ws=ws.data_ptr(),
@@ -223,7 +272,13 @@ def test_batchnorm_fwd_bwd(C, relu, residual):
   dbeta = torch.zeros(C, device=dev)
   dy = torch.empty(P, C, dtype=torch.bfloat16, device=dev)
   dres = torch.empty(P, C, dtype=torch.bfloat16, device=dev) if residual else None
-  native.run_op("bn_bwd", dict(dz=dz.data_ptr(), y=y.data_ptr(), z=z.data_ptr() if relu else None,
+  if use_mask:    # bit c of byte [row][chunk] <=> z[row, chunk*8 + c] > 0
+    bits = (zq > 0).view(P, C // 8, 8).to(torch.int32)
+    expect = (bits << torch.arange(8, device=dev)).sum(-1).to(torch.uint8)
+    assert torch.equal(mask.view(P, C // 8), expect)
+  native.run_op("bn_bwd", dict(dz=dz.data_ptr(), y=y.data_ptr(),
+                               z=z.data_ptr() if relu and not use_mask else None,
+                               mask=mask.data_ptr() if use_mask else None,
                                mean=saved.data_ptr(), invstd=saved.data_ptr() + 4 * C, gamma=gamma.data_ptr(),
                                dgamma=dgamma.data_ptr(), dbeta=dbeta.data_ptr(), dy=dy.data_ptr(),
                                dres=dres.data_ptr() if residual else None, ws=ws.data_ptr(), P=P, C=C))
