@@ -108,6 +108,10 @@ def define_keras_flags(dynamic_loss_scale=True):
   f.DEFINE_boolean("enable_get_next_as_optional", False,
                    "Allow a final partial batch in the input pipeline.")
   # Extensions of this framework (not in the reference).
+  f.DEFINE_string("ps_hosts", None, "Comma-separated host:port list of parameter-server tasks "
+                  "(with --worker_hosts, --task_type, --task_index: a TF_CONFIG on the "
+                  "command line).")
+  f.DEFINE_string("task_type", None, "ps | worker | chief: job of this process in the cluster.")
   f.DEFINE_string("executor", "auto", "auto | hip | torch: execution back end.")
   f.DEFINE_integer("seed", 0, "Seed of the variable initialisers.")
   f.DEFINE_string("resume", None, "Keras-layout HDF5 checkpoint to restore before training.")
@@ -115,8 +119,8 @@ def define_keras_flags(dynamic_loss_scale=True):
                    "Gradient fusion bucket size in MB (overrides --num_packs).")
   f.DEFINE_boolean("use_hip_graph", True, "Replay the training step as a captured hipGraph "
                    "when the strategy allows it.")
-  f.DEFINE_boolean("deterministic", False, "Check that replicas hold identical gradients "
-                   "after the all-reduce (debug aid).")
+  f.DEFINE_boolean("deterministic", False, "Fixed-order BatchNorm statistics, and a check "
+                   "that replicas hold identical gradients after the all-reduce (debug aid).")
 
 
 def data_delay_prefetch():

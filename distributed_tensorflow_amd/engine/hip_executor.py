@@ -81,7 +81,7 @@ class HipExecutor:
     # sweep over the activations less, summation order not fixed) or by the separate
     # deterministic sweep
     if fused_bn_stats is None:
-      fused_bn_stats = os.environ.get("DTF_FUSED_BN_STATS", "1") != "0"
+      fused_bn_stats = os.environ.get("DTF_BN_FUSED_STATS", "1") != "0"
     self.fused_bn_stats = fused_bn_stats
     self._keep: List[torch.Tensor] = []      # owns every planned buffer
     self._graph_stream: Optional[torch.cuda.Stream] = None

@@ -99,8 +99,13 @@ def parse_tf_config(text: Optional[str] = None) -> Optional[dict]:
   return cfg
 
 
-def configure_cluster(worker_hosts: Optional[str] = None, task_index: int = -1) -> int:
+def configure_cluster(worker_hosts: Optional[str] = None, task_index: int = -1,
+                      ps_hosts: Optional[str] = None, task_type: Optional[str] = None) -> int:
   """Sets `TF_CONFIG` from flags when needed and returns the number of workers.
+
+  `ps_hosts` / `task_type` extend the reference's two flags so that a parameter-server
+  cluster (`{'cluster': {'ps': [...], 'worker': [...]}, 'task': {...}}`, the literal at the top
+  of `ps_server/resnet_imagenet_main_dist_ps_0.py:40-50`) can be given on the command line.
 
   Behaviour of the reference's `distribution_utils.configure_cluster`
   (call site `resnet_imagenet_main.py:109-110`): an existing `TF_CONFIG` wins and
@@ -117,10 +122,15 @@ def configure_cluster(worker_hosts: Optional[str] = None, task_index: int = -1) 
     n = len(workers)
     if n > 1 and task_index < 0:
       raise ValueError("Must specify task_index when number of workers > 1")
-    task_index = 0 if n == 1 else task_index
+    task_index = 0 if n == 1 and task_index < 0 else task_index
+    cluster = {"worker": workers}
+    if ps_hosts:
+      cluster = {"ps": [h.strip() for h in ps_hosts.split(",") if h.strip()], "worker": workers}
+    task_type = task_type or "worker"
+    if task_type not in cluster or not 0 <= task_index < len(cluster[task_type]):
+      raise ValueError("task %s/%d is not part of the cluster %s" % (task_type, task_index, cluster))
     os.environ["TF_CONFIG"] = json.dumps({
-        "cluster": {"worker": workers},
-        "task": {"type": "worker", "index": task_index}})
+        "cluster": cluster, "task": {"type": task_type, "index": task_index}})
     return n
   return 1
 

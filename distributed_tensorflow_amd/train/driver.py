@@ -65,7 +65,18 @@ def maybe_launch(flags_obj, argv) -> Optional[int]:
   if "RANK" in os.environ:
     return None
   n = strategy_lib.strategy_needs_launch(ds, flags_obj.num_gpus)
+  _configure_cluster(flags_obj)
   tfc = cluster_lib.parse_tf_config()
+  if tfc is not None and ds == "multi_worker_mirrored" and flags_obj.num_gpus > 1:
+    # One TF "worker" task with several GPUs: fan out into one rank per GPU; the task's
+    # position in the cluster gives the node rank, the first task's address the rendezvous.
+    task = cluster_lib.resolve_task(gpus_per_task=flags_obj.num_gpus)
+    tasks = [t for t in task.cluster.ordered_tasks() if t[0] != "ps"]
+    node = tasks.index((task.job, task.task_index))
+    logging.info("multi_worker_mirrored: task %s/%d launches %d local ranks (node %d of %d)",
+                 task.job, task.task_index, flags_obj.num_gpus, node, len(tasks))
+    return launch_lib.launch(argv, flags_obj.num_gpus, master_addr=task.master_addr,
+                             master_port=task.master_port, nnodes=len(tasks), node_rank=node)
   if ds == "parameter_server" and tfc is None:
     # Single command: 1 PS + (num_gpus - 1) workers on this node, one rank per GPU.
     world = max(flags_obj.num_gpus, 2)
@@ -77,8 +88,15 @@ def maybe_launch(flags_obj, argv) -> Optional[int]:
   return None
 
 
+def _configure_cluster(flags_obj) -> int:
+  return cluster_lib.configure_cluster(
+      flags_obj.worker_hosts, flags_obj.task_index,
+      ps_hosts=getattr(flags_obj, "ps_hosts", None),
+      task_type=getattr(flags_obj, "task_type", None))
+
+
 def _make_strategy(flags_obj, use_horovod: bool):
-  num_workers = cluster_lib.configure_cluster(flags_obj.worker_hosts, flags_obj.task_index)
+  num_workers = _configure_cluster(flags_obj)
   if use_horovod:
     return None, num_workers
   bucket_bytes = None
@@ -194,7 +212,9 @@ def run_classifier(flags_obj, cfg: DatasetConfig, use_horovod: bool = False):
     else:
       spec = cfg.model_fn()
     model = Model(spec, strategy=strategy, dtype=dtype, device=device, seed=flags_obj.seed,
-                  executor=flags_obj.executor, data_format=data_format)
+                  executor=flags_obj.executor, data_format=data_format,
+                  use_hip_graph=None if flags_obj.use_hip_graph else False,
+                  deterministic=flags_obj.deterministic)
     model.compile(loss=cfg.loss, optimizer=optimizer,
                   metrics=[cfg.accuracy_metric] if flags_obj.report_accuracy_metrics else None,
                   run_eagerly=flags_obj.run_eagerly,

@@ -47,7 +47,11 @@ class Model:
 
   def __init__(self, spec: ModelSpec, strategy=None, dtype: str = "fp32",
                device: Optional[torch.device] = None, seed: int = 0,
-               executor: str = "auto", data_format: str = "channels_last"):
+               executor: str = "auto", data_format: str = "channels_last",
+               use_hip_graph: Optional[bool] = None, deterministic: bool = False):
+    """`use_hip_graph`: replay the native training step as a captured hipGraph (None: the
+    executor's default).  `deterministic`: fixed-order BatchNorm statistics, and after every
+    gradient all-reduce the replicas compare a checksum of the reduced gradients."""
     self.spec = spec
     self.name = spec.name
     self.strategy = strategy
@@ -67,6 +71,8 @@ class Model:
     self.metrics_names: List[str] = ["loss"]
     self._acc_name: Optional[str] = None
     self.stop_training = False
+    self.use_hip_graph = use_hip_graph
+    self.deterministic = bool(deterministic)
     self._reducer = None
     self._buckets = None
     self._synced_initial = False
@@ -112,7 +118,9 @@ class Model:
     if ex is None:
       if self.executor_kind == "hip":
         from ..engine.hip_executor import HipExecutor  # pylint: disable=import-outside-toplevel
-        ex = HipExecutor(self.spec, self.store, batch, self.dtype, self._bucket_list())
+        ex = HipExecutor(self.spec, self.store, batch, self.dtype, self._bucket_list(),
+                         use_graph=self.use_hip_graph,
+                         fused_bn_stats=False if self.deterministic else None)
       else:
         ex = TorchExecutor(self.spec, self.store, batch, self.dtype, self._bucket_list())
       self._executors[batch] = ex
@@ -175,8 +183,27 @@ class Model:
                                   red.on_bucket_ready if red is not None else None)
     if red is not None:
       red.finish()
+      if self.deterministic:
+        self._check_replica_gradients()
     self.optimizer.apply_gradients(self.store, red.divisor if red is not None else 1.0, ex)
     return loss, correct
+
+  def _check_replica_gradients(self):
+    """Every replica must hold bit-identical gradients after the all-reduce: compares a
+    (sum, sum of squares) checksum of the flat gradient buffer across ranks."""
+    comm = getattr(self._reducer, "comm", None)
+    if comm is None or comm.world_size <= 1:
+      return
+    g = self.store.grads.double()
+    mine = torch.stack([g.sum(), (g * g).sum()])
+    lo, hi = mine.clone(), mine.clone()
+    import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if not torch.equal(lo, hi) or not bool(torch.isfinite(mine).all()):
+      raise RuntimeError("replicas disagree on the reduced gradients at iteration %d: "
+                         "checksum min %s max %s" % (self.optimizer.iterations, lo.tolist(),
+                                                     hi.tolist()))
 
   def test_on_batch(self, images, labels):
     ex = self._executor(int(images.shape[0]))

@@ -120,6 +120,34 @@ strat.barrier()
   assert torch.allclose(torch.tensor(res[0]["conv1"]), ref_c, rtol=1e-3, atol=1e-6)
 
 
+def test_deterministic_replica_gradient_check(tmp_path):
+  """`deterministic=True` compares gradient checksums across replicas after the all-reduce
+  and raises when a replica's buffer was tampered with."""
+  body = COMMON + """
+strat = S.get_distribution_strategy("mirrored", num_gpus=0)
+m = Model(models.resnet20(), strategy=strat, dtype="fp32", seed=1, deterministic=True)
+m.compile(SGD(0.05, momentum=0.9), "sparse_categorical_crossentropy")
+xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+m.train_on_batch(xs, ys)                   # passes: all-reduced gradients agree
+red = m._grad_reducer()
+orig = red.finish
+def corrupt():
+  orig()
+  if rank == 1:
+    m.store.grads[7] += 1.0
+red.finish = corrupt
+caught = False
+try:
+  m.train_on_batch(xs, ys)
+except RuntimeError as e:
+  caught = "replicas disagree" in str(e)
+save({"caught": caught})
+strat.barrier()
+"""
+  res = _run_ranks(tmp_path, body, 2)
+  assert res[0]["caught"] and res[1]["caught"]
+
+
 def test_multi_worker_mirrored_from_tf_config(tmp_path):
   """Rank and world size come from a TF_CONFIG cluster spec (two 'workers' on localhost)."""
   sys.path.insert(0, ROOT)

@@ -108,3 +108,47 @@ def test_imagenet_resnet50_native_end_to_end(tmp_path, small_validation):
       extra_flags=["-batch_size", "16", "-train_steps", "3", "-num_gpus", "1", "-dtype", "bf16",
                    "-distribution_strategy", "one_device", "-log_steps", "1"], max_train=None)
   assert stats["loss"] > 0 and "avg_exp_per_second" in stats
+
+
+def _free_ports(n):
+  import socket
+  socks = [socket.socket() for _ in range(n)]
+  for s in socks:
+    s.bind(("127.0.0.1", 0))
+  ports = [s.getsockname()[1] for s in socks]
+  for s in socks:
+    s.close()
+  return ports
+
+
+def _run_pair(tmp_path, cmds, timeout=300):
+  import subprocess
+  env = dict(os.environ, OMP_NUM_THREADS="2")
+  for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TF_CONFIG"):
+    env.pop(k, None)
+  procs = [subprocess.Popen([sys.executable] + c, env=env, cwd=str(tmp_path),
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for c in cmds]
+  outs = [p.communicate(timeout=timeout)[0].decode()[-3000:] for p in procs]
+  assert all(p.returncode == 0 for p in procs), "\n=====\n".join(outs)
+  return outs
+
+
+def test_multi_worker_variant_drivers_on_localhost(tmp_path):
+  """`resnet_cifar_main_dist.py` + `_dist_1.py`: the reference's two-terminal localhost
+  rehearsal of multi_worker_mirrored (`README.md:120-124`)."""
+  p0, p1 = _free_ports(2)
+  common_args = ["--use_synthetic_data", "--num_gpus", "0", "--batch_size", "8", "--train_steps",
+                 "2", "--skip_eval", "--worker_hosts", "localhost:%d,localhost:%d" % (p0, p1)]
+  outs = _run_pair(tmp_path, [[os.path.join(ROOT, "resnet_cifar_main_dist.py")] + common_args,
+                              [os.path.join(ROOT, "resnet_cifar_main_dist_1.py")] + common_args])
+  assert all("Run stats" in o and "'loss'" in o for o in outs)
+
+
+def test_parameter_server_variant_driver_on_localhost(tmp_path):
+  """ps task + worker task of `resnet_cifar_main_dist_ps.py`; the ps task exits by itself."""
+  p0, p1 = _free_ports(2)
+  args = ["--use_synthetic_data", "--num_gpus", "0", "--batch_size", "8", "--train_steps", "3",
+          "--skip_eval", "--ps_hosts", "localhost:%d" % p0, "--worker_hosts", "localhost:%d" % p1]
+  script = os.path.join(ROOT, "resnet_cifar_main_dist_ps.py")
+  outs = _run_pair(tmp_path, [[script] + args + ["--task_type", "ps"], [script] + args])
+  assert "'loss'" in outs[1] and "Run stats" in outs[0]
