@@ -33,7 +33,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 import torch
 
 from ..models.graph import ModelSpec, Op
-from ..ops import native
+from ..ops import autotune, native
 from ..ops.conv_plan import ConvGeom, round_up
 from ..utils import logging
 from .params import Bucket, ParamStore
@@ -188,8 +188,9 @@ class HipExecutor:
         self._bn_stats_off[b.name] = so
         so += self.STATS_REPLICAS * 2 * c
       if b.attrs["relu"]:
-        self._bn_mask[b.name] = self._alloc((acts[b.output].numel() // 8,), torch.uint8,
-                                            zero=False)
+        # written as 32-bit words: rounded up to a multiple of 4 bytes
+        self._bn_mask[b.name] = self._alloc((round_up(acts[b.output].numel() // 8, 4),),
+                                            torch.uint8, zero=False)
     self.bn_stats = self._alloc((max(so, 1),), torch.float32)
     self._stats_of_conv = {b.inputs[0]: self.bn_stats.data_ptr() + 4 * self._bn_stats_off[b.name]
                            for b in bn_ops if b.name in self._bn_stats_off}
@@ -201,6 +202,7 @@ class HipExecutor:
     self._build_forward(self.fwd_plan, training=True)
     self._build_forward(self.eval_plan, training=False)
     self._build_backward(consumers)
+    autotune.save()
     self.probs = None
     nbytes = sum(t.numel() * t.element_size() for t in self._keep)
     logging.info("HipExecutor planned %s for batch %d: %d fwd + %d bwd launches, %.2f GB of "
@@ -243,6 +245,12 @@ class HipExecutor:
     self._pack_args = dict(params=self.store.params.data_ptr(), packed=self.packed.data_ptr(),
                            descs=self.pack_descs.data_ptr(), ndesc=len(descs), nblocks=blk)
 
+  def _add(self, plan, kind: str, desc: Dict, name: str):
+    """plan.add with the measured tile configuration of this shape, when one is known."""
+    if kind in ("conv", "wgrad"):
+      desc = autotune.apply(kind, desc)
+    plan.add(kind, desc, name)
+
   def _wf_ptr(self, name):
     return self.packed.data_ptr() + 2 * self._wf[name]
 
@@ -264,11 +272,11 @@ class HipExecutor:
       if op.kind == "conv":
         g = self.geoms[op.name]
         st = self._stats_of_conv.get(op.output) if training else None
-        plan.add("conv", g.fwd(x.data_ptr(), self._wf_ptr(op.name), acts[op.output].data_ptr(),
+        self._add(plan, "conv", g.fwd(x.data_ptr(), self._wf_ptr(op.name), acts[op.output].data_ptr(),
                                stats=st, stats_replicas=self.STATS_REPLICAS), op.name)
       elif op.kind == "dense":
         g = self.geoms[op.name]
-        plan.add("conv", g.fwd(x.data_ptr(), self._wf_ptr(op.name), acts[op.output].data_ptr(),
+        self._add(plan, "conv", g.fwd(x.data_ptr(), self._wf_ptr(op.name), acts[op.output].data_ptr(),
                                bias=self._var_ptr(op.name + "/bias")), op.name)
       elif op.kind == "bn":
         C = at["channels"]
@@ -365,12 +373,12 @@ class HipExecutor:
         g = self.geoms[op.name]
         plan.add("colsum", dict(x=dout.data_ptr(), out=self._var_ptr(op.name + "/bias", "grad"),
                                 N=N, C=g.Cout, ld=g.ldc), op.name + "/dbias")
-        plan.add("wgrad", g.wgrad(acts[xname].data_ptr(), dout.data_ptr(),
+        self._add(plan, "wgrad", g.wgrad(acts[xname].data_ptr(), dout.data_ptr(),
                                   self._var_ptr(op.name + "/kernel", "grad")), op.name + "/wgrad")
         dx = grad_buf(xname)
         for d in g.dgrad(dout.data_ptr(), self._wd_ptr(op.name), dx.data_ptr(),
                          accumulate=xname in written):
-          plan.add("conv", d, op.name + "/dgrad")
+          self._add(plan, "conv", d, op.name + "/dgrad")
         written.add(xname)
         done([op.name + "/kernel", op.name + "/bias"])
       elif op.kind == "mean":
@@ -420,13 +428,13 @@ class HipExecutor:
         done([op.name + "/gamma", op.name + "/beta"])
       elif op.kind == "conv":
         g = self.geoms[op.name]
-        plan.add("wgrad", g.wgrad(acts[xname].data_ptr(), dout.data_ptr(),
+        self._add(plan, "wgrad", g.wgrad(acts[xname].data_ptr(), dout.data_ptr(),
                                   self._var_ptr(op.name + "/kernel", "grad")), op.name + "/wgrad")
         if op is not first_conv:
           dx = grad_buf(xname)
           for d in g.dgrad(dout.data_ptr(), self._wd_ptr(op.name), dx.data_ptr(),
                            accumulate=xname in written):
-            plan.add("conv", d, op.name + "/dgrad")
+            self._add(plan, "conv", d, op.name + "/dgrad")
           written.add(xname)
         done([op.name + "/kernel"])
     if seg_begin < plan.size() or not self._segments:

@@ -1,0 +1,164 @@
+"""Per-shape tile selection for the convolution kernels, measured on the device.
+
+The reference leaves algorithm choice to cuDNN's autotuner (TensorFlow runs every convolution
+algorithm once per new shape and keeps the fastest).  The counterpart here: for every distinct
+convolution descriptor of a planned model the candidate tile configurations (and, for the
+weight gradient, split-K factors) are timed with HIP events on the real buffers, and the
+winner is recorded under a shape signature.  Results are cached in `tuned_gfx950.json` next to
+this file - the file in the tree holds the shapes of the bundled models measured on an MI355X,
+so a normal run only does dictionary look-ups; shapes that are not in the cache fall back to the
+heuristics of `conv_plan.pick_fwd_cfg` / `pick_wgrad_cfg` unless tuning is switched on with
+`DTF_AUTOTUNE=1` (new entries are then written to `DTF_AUTOTUNE_OUT` or the cache file;
+`DTF_AUTOTUNE_CACHE` reads another cache file, `DTF_AUTOTUNE_IGNORE_CACHE=1` starts empty).
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, List, Optional, Tuple
+
+from . import conv_plan
+
+__all__ = ["signature", "lookup", "apply", "tune", "save", "enabled", "CACHE_PATH"]
+
+CACHE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
+_POINTERS = ("in", "wgt", "out", "addend", "bias", "stats", "x", "dy", "dw")
+_IGNORED = _POINTERS + ("cfg", "splits", "stats_replicas")
+_cache: Optional[Dict[str, Dict[str, int]]] = None
+_dirty = False
+
+
+def enabled() -> bool:
+  return os.environ.get("DTF_AUTOTUNE", "0") == "1"
+
+
+def _load() -> Dict[str, Dict[str, int]]:
+  global _cache
+  if _cache is None:
+    _cache = {}
+    path = os.environ.get("DTF_AUTOTUNE_CACHE") or CACHE_PATH
+    if os.environ.get("DTF_AUTOTUNE_IGNORE_CACHE", "0") != "1" and os.path.exists(path):
+      with open(path) as f:
+        _cache = json.load(f)
+  return _cache
+
+
+def signature(kind: str, desc: Dict) -> str:
+  """Shape key of a descriptor: every integer field, plus which optional tensors are present."""
+  parts = [kind]
+  for k in sorted(desc):
+    if k in _IGNORED:
+      continue
+    parts.append("%s=%s" % (k, desc[k]))
+  for k in ("addend", "bias", "stats"):
+    if desc.get(k) is not None:
+      parts.append("+" + k)
+  return "|".join(parts)
+
+
+def lookup(kind: str, desc: Dict) -> Optional[Dict[str, int]]:
+  return _load().get(signature(kind, desc))
+
+
+def _fwd_candidates(desc: Dict) -> List[int]:
+  cout = desc["Cout"]
+  if cout <= 16:
+    return [3, 2]
+  if cout <= 32:
+    return [2, 1]
+  if cout <= 64:
+    return [1, 5, 0]
+  return [0, 6, 4, 5, 1]
+
+
+def _wgrad_candidates(desc: Dict) -> List[Tuple[int, int]]:
+  cout = desc["Cout"]
+  ktotal = desc["TI"] * desc["TJ"] * desc["Ctap"]
+  P = desc["N"] * desc["OH"] * desc["OW"]
+  if cout <= 16:
+    cfgs = [5, 7]
+  elif cout <= 32:
+    cfgs = [4, 6]
+  elif cout <= 64:
+    cfgs = [1, 3]
+  else:
+    cfgs = [0, 2, 1]
+  if ktotal <= 64:
+    cfgs = [c for c in cfgs if conv_plan.WGRAD_CFGS[c][0] <= 64] or cfgs
+  out = []
+  max_splits = max(P // 256, 1)
+  for c in cfgs:
+    bkk, bco = conv_plan.WGRAD_CFGS[c]
+    tiles = -(-ktotal // bkk) * -(-cout // bco)
+    seen = set()
+    for target in (192, 256, 384, 512, 768, 1024, 1536):
+      s = max(1, min(-(-target // tiles), max_splits))
+      if s not in seen:
+        seen.add(s)
+        out.append((c, s))
+  return out
+
+
+def _time_op(kind: str, desc: Dict, iters: int = 10) -> float:
+  import torch  # pylint: disable=import-outside-toplevel
+  from . import native  # pylint: disable=import-outside-toplevel
+  for _ in range(2):
+    native.run_op(kind, desc)
+  start = torch.cuda.Event(enable_timing=True)
+  stop = torch.cuda.Event(enable_timing=True)
+  start.record()
+  for _ in range(iters):
+    native.run_op(kind, desc)
+  stop.record()
+  stop.synchronize()
+  return start.elapsed_time(stop) / iters
+
+
+def tune(kind: str, desc: Dict) -> Dict[str, int]:
+  """Times the candidates of one descriptor on the current device; records and returns the best."""
+  global _dirty
+  best, best_t = None, float("inf")
+  trial = dict(desc)
+  if kind == "conv":
+    for c in _fwd_candidates(desc):
+      trial["cfg"] = c
+      t = _time_op(kind, trial)
+      if t < best_t:
+        best, best_t = {"cfg": c}, t
+  elif kind == "wgrad":
+    for c, s in _wgrad_candidates(desc):
+      trial["cfg"], trial["splits"] = c, s
+      t = _time_op(kind, trial)
+      if t < best_t:
+        best, best_t = {"cfg": c, "splits": s}, t
+  else:
+    raise ValueError("nothing to tune for op kind %r" % kind)
+  best["us"] = round(best_t * 1000.0, 1)
+  _load()[signature(kind, desc)] = best
+  _dirty = True
+  return best
+
+
+def apply(kind: str, desc: Dict) -> Dict:
+  """Returns `desc` with the tuned configuration filled in (tuning it first when enabled)."""
+  hit = lookup(kind, desc)
+  if hit is None and enabled():
+    hit = tune(kind, desc)
+  if hit is not None:
+    desc = dict(desc)
+    desc["cfg"] = hit["cfg"]
+    if "splits" in hit:
+      desc["splits"] = hit["splits"]
+  return desc
+
+
+def save(path: Optional[str] = None):
+  """Writes the cache if tuning added entries."""
+  global _dirty
+  if not _dirty:
+    return
+  path = path or os.environ.get("DTF_AUTOTUNE_OUT") or CACHE_PATH
+  os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+  with open(path, "w") as f:
+    json.dump(_load(), f, indent=0, sort_keys=True)
+  _dirty = False

@@ -34,7 +34,7 @@
 namespace {
 
 constexpr int TPB = 256;
-constexpr int MAX_PARTIAL_BLOCKS = 512;   // rows of the partial-sum workspace
+constexpr int MAX_PARTIAL_BLOCKS = 1024;   // rows of the partial-sum workspace
 
 // Per-block partial sums: threads that own the same channel chunk (same tid % tpr) are summed
 // through LDS and the block writes one row [NV/8 quantities][C] of the workspace with plain
@@ -187,29 +187,41 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
       shift[c] = a.beta[ch] - a.mm[ch] * scale[c];
     }
   }
-  for (int row = blockIdx.x * rpb + rowid; row < a.P; row += gridDim.x * rpb) {
+  // The trip count is uniform per block (row0 is the block's first row of the pass) so that
+  // the four lanes of a quad can merge their mask bytes into one 32-bit store: the byte of
+  // thread t in this pass sits at  row0 * tpr + t,  and row0 * tpr is a multiple of 256.
+  for (int row0 = blockIdx.x * rpb; row0 < a.P; row0 += gridDim.x * rpb) {
+    const int row = row0 + rowid;
+    const bool valid = row < a.P;
     const size_t off = (size_t)row * C + chunk * 8;
     float f[8];
-    unpack8(*reinterpret_cast<const u32x4*>(a.y + off), f);
+    uint32_t bits = 0;
+    if (valid) {
+      unpack8(*reinterpret_cast<const u32x4*>(a.y + off), f);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) f[c] = f[c] * scale[c] + shift[c];
-    if (a.res) {
-      float r[8];
-      unpack8(*reinterpret_cast<const u32x4*>(a.res + off), r);
+      for (int c = 0; c < 8; ++c) f[c] = f[c] * scale[c] + shift[c];
+      if (a.res) {
+        float r[8];
+        unpack8(*reinterpret_cast<const u32x4*>(a.res + off), r);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) f[c] += r[c];
-    }
-    if (a.relu) {
-      if (a.mask) {
-        uint32_t bits = 0;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) bits |= (f[c] > 0.f ? 1u : 0u) << c;
-        a.mask[(size_t)row * tpr + chunk] = (uint8_t)bits;
+        for (int c = 0; c < 8; ++c) f[c] += r[c];
       }
+      if (a.relu) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) f[c] = fmaxf(f[c], 0.f);
+        for (int c = 0; c < 8; ++c) {
+          bits |= (f[c] > 0.f ? 1u : 0u) << c;
+          f[c] = fmaxf(f[c], 0.f);
+        }
+      }
+      *reinterpret_cast<u32x4*>(a.z + off) = pack8(f);
     }
-    *reinterpret_cast<u32x4*>(a.z + off) = pack8(f);
+    if (a.relu && a.mask) {
+      uint32_t w = bits << (8 * (threadIdx.x & 3));
+      w |= __shfl_xor(w, 1);
+      w |= __shfl_xor(w, 2);
+      if ((threadIdx.x & 3) == 0 && valid)
+        *reinterpret_cast<uint32_t*>(a.mask + (size_t)row0 * tpr + threadIdx.x) = w;
+    }
   }
 }
 
@@ -236,18 +248,17 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
   float part[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) part[i] = 0.f;
-  for (int row = blockIdx.x * rpb + rowid; row < a.P; row += gridDim.x * rpb) {
-    const size_t off = (size_t)row * C + chunk * 8;
+  const int mode = a.mask ? 2 : (a.z ? 1 : 0);
+  auto accumulate = [&](const u32x4& gv, const u32x4& yq, const u32x4& zq, uint32_t bits) {
     float g[8], yv[8];
-    unpack8(*reinterpret_cast<const u32x4*>(a.dz + off), g);
-    unpack8(*reinterpret_cast<const u32x4*>(a.y + off), yv);
-    if (a.mask) {
-      const uint32_t bits = a.mask[(size_t)row * tpr + chunk];
+    unpack8(gv, g);
+    unpack8(yq, yv);
+    if (mode == 2) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) g[c] = (bits >> c) & 1u ? g[c] : 0.f;
-    } else if (a.z) {
+    } else if (mode == 1) {
       float zv[8];
-      unpack8(*reinterpret_cast<const u32x4*>(a.z + off), zv);
+      unpack8(zq, zv);
 #pragma unroll
       for (int c = 0; c < 8; ++c) g[c] = zv[c] > 0.f ? g[c] : 0.f;
     }
@@ -256,6 +267,30 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
       part[c] += g[c] * ((yv[c] - mean[c]) * invstd[c]);   // dgamma
       part[8 + c] += g[c];                                  // dbeta
     }
+  };
+  const int stride = gridDim.x * rpb;
+  int row = blockIdx.x * rpb + rowid;
+  for (; row + 3 * stride < a.P; row += 4 * stride) {      // four rows of loads in flight
+    u32x4 gv[4], yq[4], zq[4];
+    uint32_t bits[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t off = (size_t)(row + u * stride) * C + chunk * 8;
+      gv[u] = *reinterpret_cast<const u32x4*>(a.dz + off);
+      yq[u] = *reinterpret_cast<const u32x4*>(a.y + off);
+      zq[u] = mode == 1 ? *reinterpret_cast<const u32x4*>(a.z + off) : u32x4{0, 0, 0, 0};
+      bits[u] = mode == 2 ? a.mask[(size_t)(row + u * stride) * tpr + chunk] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) accumulate(gv[u], yq[u], zq[u], bits[u]);
+  }
+  for (; row < a.P; row += stride) {
+    const size_t off = (size_t)row * C + chunk * 8;
+    const u32x4 gv = *reinterpret_cast<const u32x4*>(a.dz + off);
+    const u32x4 yq = *reinterpret_cast<const u32x4*>(a.y + off);
+    const u32x4 zq = mode == 1 ? *reinterpret_cast<const u32x4*>(a.z + off) : u32x4{0, 0, 0, 0};
+    const uint32_t bits = mode == 2 ? a.mask[(size_t)row * tpr + chunk] : 0u;
+    accumulate(gv, yq, zq, bits);
   }
   block_reduce_to_partials<16>(part, tpr, chunk, rowid, a.ws + (size_t)blockIdx.x * 2 * C, C);
 }

@@ -12,7 +12,9 @@
 // ragged (dense layer: 1001 outputs).
 //
 // GEMM view: M = N*OH*OW pixels, N = Cout, K = taps*Ctap.  Block tile BM pixels x
-// BN channels x BK=32, 256 threads = 4 waves arranged WAVES_M x WAVES_N.  The MFMA
+// BN channels x BK=32, 4 or 8 waves arranged WAVES_M x WAVES_N (a 128x128 tile moves 16 KiB
+// from L2 per 1 MFLOP - 64 FLOP/B, which caps the chip near 1.1 PFLOP/s at the ~18 TB/s the
+// L2s deliver; the 8-wave 256x128 tile reaches 96 FLOP/B at the same registers per wave).  The MFMA
 // A operand is the *weight* tile and the B operand the *pixel* tile, so that a
 // lane ends up holding 4*NR consecutive output channels of one pixel and stores
 // them with 16-byte writes, no LDS transpose in the epilogue.
@@ -43,8 +45,6 @@ constexpr int BK = 32;
 // 16 bytes of zeros in global memory: the source of every masked direct-to-LDS load.
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};
 
-// Second launch-bound argument = waves per SIMD the register allocation must allow: 4 blocks
-// of 4 waves per CU (64 accumulator registers + ~60 others fit the 128-register budget).
 // Sum over the 16 lanes that share lane/16 (the 16 pixels of an MFMA column block), leaving
 // the totals scattered over those lanes: a halving butterfly - at step T a lane keeps one
 // half of its values and hands the other half to lane ^ (1 << T) - so NV values cost NV - 1
@@ -71,15 +71,32 @@ __device__ __forceinline__ void butterfly16(float (&v)[NV], int fr) {
 }
 
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool POINTWISE>
-__global__ __launch_bounds__(256, 4) void conv_igemm_kernel(const ConvParams p) {
+// Addressing modes of the gather (template parameter MODE):
+//   GENERIC    every K-step decodes its k index into (tap i, tap j, channel) per lane - needed
+//              when a 32-wide K-step straddles taps (Ctap not a multiple of 32: CIFAR stages,
+//              ragged K);
+//   POINTWISE  1x1 / dense: a plain GEMM, the pixel index is the row;
+//   TAPLOOP    Ctap % 32 == 0: a K-step never leaves its tap, so bounds checks and address
+//              arithmetic run once per tap and a K-step only bumps one 64-bit pointer per
+//              load (about 12 VALU instructions per step instead of 60: with 16 MFMAs per step
+//              and four waves per SIMD the generic loop is VALU-issue bound).
+constexpr int GENERIC = 0, POINTWISE_MODE = 1, TAPLOOP = 2;
+
+// Second launch-bound argument = waves per SIMD the register allocation must allow: 4 blocks
+// of 4 waves per CU (64 accumulator registers + ~60 others fit the 128-register budget).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 4)
+void conv_igemm_kernel(const ConvParams p) {
+  constexpr bool POINTWISE = MODE == POINTWISE_MODE;
+  constexpr int NW = WAVES_M * WAVES_N;             // waves per block: 4, or 8 for the 256x128 tile
+  constexpr int RPP = 16 * NW;                      // tile rows filled per pass (16 per wave)
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MR = WM / 16, NR = WN / 16;
-  constexpr int XV = BM / 64;                       // 16-byte pixel-tile vectors per thread
-  constexpr int WV = (BN + 63) / 64;                // 16-byte weight-tile vectors per thread
+  constexpr int XV = BM / RPP;                      // 16-byte pixel-tile vectors per thread
+  constexpr int WV = (BN + RPP - 1) / RPP;          // 16-byte weight-tile vectors per thread
   constexpr int XBYTES = BM * 64, WBYTES = BN * 64;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
-  static_assert(BM % 64 == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
+  static_assert(BM % RPP == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
 
   __shared__ __attribute__((aligned(16))) uint8_t smem[2 * (XBYTES + WBYTES)];
 
@@ -104,14 +121,14 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(const ConvParams p) 
   // at row l/4, 16-byte slot l%4.  The XOR swizzle therefore moves to the *source*: the lane
   // that owns physical slot s of a row fetches logical K-chunk s ^ g(row).  Out-of-image
   // taps, rows past M and channels past Cout fetch from a 16-byte page of zeros.
-  const int lrow = tid >> 2;       // 0..63: tile row of this lane within a 64-row group
+  const int lrow = tid >> 2;       // tile row of this lane within a pass of RPP rows
   const int kvx = (tid & 3) ^ ((-(lrow >> 2)) & 3);            // logical K-chunk, pixel tile
   const int kvw = (tid & 3) ^ ((-(lrow / (4 * NR))) & 3);      // logical K-chunk, weight tile
   int xbase[XV];                   // POINTWISE: pixel row index; else pixel index base n*H*W
   int xh[XV], xw[XV];              // base input coordinates (before the tap offset)
 #pragma unroll
   for (int r = 0; r < XV; ++r) {
-    const int m = m0 + lrow + 64 * r;
+    const int m = m0 + lrow + RPP * r;
     if (POINTWISE) {
       xbase[r] = (m < p.M) ? m : -1;
       xh[r] = xw[r] = 0;
@@ -131,6 +148,60 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(const ConvParams p) 
       }
     }
   }
+  const bf16_t* __restrict__ gin = p.in;
+  const bf16_t* __restrict__ gw = p.wgt;
+  const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_zero_page);
+
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  // ---- TAPLOOP state: one pointer (+ per-step increment: 64 bytes, or 0 on the zero page)
+  // per load, recomputed when the wave-uniform tap (tli, tlj) changes --------------------
+  const bf16_t* xptr[XV];
+  const bf16_t* wptr[WV];
+  int xinc[XV], winc[WV];
+  int tli = 0, tlj = 0, tlc = 0;                   // current tap and K-steps done inside it
+  const int steps_per_tap = p.Ctap / BK;
+  auto setup_tap = [&]() {
+#pragma unroll
+    for (int r = 0; r < XV; ++r) {
+      const int hi = xh[r] + tli * p.dhs;
+      const int wi = xw[r] + tlj * p.dws;
+      const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      xptr[r] = ok ? gin + ((size_t)(xbase[r] + hi * p.W + wi) * p.Cpix + kvx * 8) : zero_page;
+      xinc[r] = ok ? BK : 0;
+    }
+    const int wk = p.wk0 + tli * p.wsi + tlj * p.wsj + kvw * 8;
+#pragma unroll
+    for (int r = 0; r < WV; ++r) {
+      const int co = n0 + lrow + RPP * r;
+      const bool ok = co < p.Cout;
+      wptr[r] = ok ? gw + ((size_t)co * p.ldw + wk) : zero_page;
+      winc[r] = ok ? BK : 0;
+    }
+  };
+  auto issue_tile_tap = [&](int buf) {
+    uint8_t* xs = smem + buf * (XBYTES + WBYTES);
+    uint8_t* ws = xs + XBYTES;
+#pragma unroll
+    for (int r = 0; r < XV; ++r) {
+      __builtin_amdgcn_global_load_lds((gptr_t)xptr[r], (lptr_t)(xs + r * (RPP * 64) + wave * 1024), 16, 0, 0);
+      xptr[r] += xinc[r];
+    }
+#pragma unroll
+    for (int r = 0; r < WV; ++r) {
+      if (RPP * r + wave * 16 < BN) {               // wave-uniform: whole 16-row pieces only
+        __builtin_amdgcn_global_load_lds((gptr_t)wptr[r], (lptr_t)(ws + r * (RPP * 64) + wave * 1024), 16, 0, 0);
+        wptr[r] += winc[r];
+      }
+    }
+    if (++tlc == steps_per_tap) {                  // next tap (uniform branch)
+      tlc = 0;
+      if (++tlj == p.TJ) { tlj = 0; ++tli; }
+      if (tli < p.TI) setup_tap();
+    }
+  };
+
   // running decomposition of the two k indices into (tap i, tap j, channel c)
   int kkx = kvx * 8, kcx = kvx * 8, tix = 0, tjx = 0;
   int kkw = kvw * 8, kcw = kvw * 8, tiw = 0, tjw = 0;
@@ -138,13 +209,6 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(const ConvParams p) 
     while (kcx >= p.Ctap) { kcx -= p.Ctap; if (++tjx == p.TJ) { tjx = 0; ++tix; } }
     while (kcw >= p.Ctap) { kcw -= p.Ctap; if (++tjw == p.TJ) { tjw = 0; ++tiw; } }
   }
-
-  const bf16_t* __restrict__ gin = p.in;
-  const bf16_t* __restrict__ gw = p.wgt;
-  const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_zero_page);
-
-  typedef const __attribute__((address_space(1))) void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
 
   auto issue_tile = [&](int buf) {
     uint8_t* xs = smem + buf * (XBYTES + WBYTES);
@@ -162,17 +226,17 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(const ConvParams p) 
         const bool ok = kvalx && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
         src = ok ? gin + ((size_t)(xbase[r] + hi * p.W + wi) * p.Cpix + kcx) : zero_page;
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + r * 4096 + wave * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + r * (RPP * 64) + wave * 1024), 16, 0, 0);
     }
     const bool kvalw = kkw < p.Ktotal;
     const int wk = POINTWISE ? (p.wk0 + kkw) : (p.wk0 + tiw * p.wsi + tjw * p.wsj + kcw);
 #pragma unroll
     for (int r = 0; r < WV; ++r) {
-      if (64 * r + wave * 16 < BN) {               // wave-uniform: whole 16-row pieces only
-        const int co = n0 + lrow + 64 * r;
+      if (RPP * r + wave * 16 < BN) {               // wave-uniform: whole 16-row pieces only
+        const int co = n0 + lrow + RPP * r;
         const bool ok = kvalw && co < p.Cout;
         const bf16_t* src = ok ? gw + ((size_t)co * p.ldw + wk) : zero_page;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ws + r * 4096 + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ws + r * (RPP * 64) + wave * 1024), 16, 0, 0);
       }
     }
   };
@@ -209,7 +273,10 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(const ConvParams p) 
     for (int mr = 0; mr < MR; ++mr) acc[nr][mr] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int KT = (p.Ktotal + BK - 1) / BK;
-  if (KT > 0) {
+  if constexpr (MODE == TAPLOOP) {
+    setup_tap();
+    if (KT > 0) issue_tile_tap(0);
+  } else if (KT > 0) {
     issue_tile(0);
     advance_k();
   }
@@ -219,8 +286,12 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(const ConvParams p) 
     const int buf = kt & 1;
     const bool more = kt + 1 < KT;
     if (more) {                                    // next tile streams into the other buffer
-      issue_tile(buf ^ 1);                         // while this one is multiplied
-      advance_k();
+      if constexpr (MODE == TAPLOOP) {             // while this one is multiplied
+        issue_tile_tap(buf ^ 1);
+      } else {
+        issue_tile(buf ^ 1);
+        advance_k();
+      }
     }
     const uint8_t* xs = smem + buf * (XBYTES + WBYTES);
     const uint8_t* ws = xs + XBYTES;
@@ -377,11 +448,14 @@ void launch_cfg(const ConvParams& p, hipStream_t stream) {
                          p.OH == p.H && p.OW == p.W && p.OHfull == p.OH && p.OWfull == p.OW &&
                          p.Ctap <= p.Cpix;
   if (pointwise)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, true>), dim3(grid), dim3(256),
-                       0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, POINTWISE_MODE>), dim3(grid),
+                       dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
+  else if (p.Ctap % BK == 0)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, TAPLOOP>), dim3(grid),
+                       dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, false>), dim3(grid),
-                       dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, GENERIC>), dim3(grid),
+                       dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
 }
 
 }  // namespace
@@ -430,6 +504,7 @@ void launch_conv_igemm(const ConvParams& p, int cfg, hipStream_t stream) {
     case 3: launch_cfg<256, 16, 4, 1>(p, stream); break;
     case 4: launch_cfg<64, 128, 1, 4>(p, stream); break;
     case 5: launch_cfg<128, 64, 2, 2>(p, stream); break;
+    case 6: launch_cfg<256, 128, 4, 2>(p, stream); break;   // 8 waves: 1.5x the FLOP per L2 byte
     default: throw std::invalid_argument("conv_igemm: unknown tile config");
   }
 }

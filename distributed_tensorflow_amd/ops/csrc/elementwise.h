@@ -3,7 +3,8 @@
 #include "common.h"
 
 size_t bn_workspace_floats();
-// `mask` (optional): one bit per element of the ReLU mask, [P][C/8] bytes.
+// `mask` (optional): one bit per element of the ReLU mask, [P][C/8] bytes, written as 32-bit
+// words: the buffer must be 4-byte aligned with room for P*C/8 rounded up to 4 bytes.
 // `fused_replicas` > 0: `ws` holds that many rows of [2][C] sums left by the convolution.
 void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, uint8_t* mask,
                          const float* gamma, const float* beta, float* mm, float* mv,

@@ -105,7 +105,7 @@ def test_conv_fwd_dgrad_wgrad(case):
     # N, H, W, Cin, K, Cout, stride, cfg
     (4, 28, 28, 64, 3, 128, 1, 0), (4, 28, 28, 64, 1, 64, 1, 1), (3, 17, 17, 16, 3, 32, 1, 2),
     (3, 17, 17, 16, 3, 16, 2, 3), (2, 14, 14, 256, 1, 512, 1, 4), (4, 28, 28, 128, 1, 64, 1, 5),
-    (2, 9, 9, 32, 3, 72, 1, 0)])
+    (2, 9, 9, 32, 3, 72, 1, 0), (3, 28, 28, 64, 3, 128, 1, 6), (5, 14, 14, 256, 1, 200, 1, 6)])
 def test_conv_fused_bn_statistics(case):
   """The epilogue's per-channel sum / sum of squares equal those of the stored bf16 output,
   followed by the BatchNorm finalize that consumes the replicas."""
@@ -145,6 +145,38 @@ def test_conv_fused_bn_statistics(case):
     torch.cuda.synchronize()
     ref = (o - o.mean(0)) * torch.rsqrt(o.var(0, unbiased=False) + 1e-5)
     assert torch.allclose(z.float(), ref, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 4, 5, 6])
+@pytest.mark.parametrize("shape", [(3, 19, 19, 64, 3, 136, 2), (2, 15, 15, 96, 1, 264, 1),
+                                   (2, 14, 14, 32, 3, 128, 1)])
+def test_conv_every_tile_config(cfg, shape):
+  """Forward and data gradient give the same result under every block tile (ragged M and
+  Cout, strided parity launches, all three addressing modes)."""
+  native = _native()
+  N, H, W, Cin, K, Cout, stride = shape
+  dev = torch.device("cuda")
+  gen = torch.Generator(device="cpu").manual_seed(cfg * 100 + H)
+  pad = same_padding(H, K, stride) + same_padding(W, K, stride)
+  g = ConvGeom(N, H, W, Cin, K, K, Cout, stride, pad)
+  x = _bf(torch.randn(N, H, W, Cin, generator=gen)).to(dev)
+  w = (torch.randn(K, K, Cin, Cout, generator=gen) * (1.0 / math.sqrt(K * K * Cin))).to(dev)
+  wq = _bf(w).float()
+  out = torch.full(g.output_shape, float("nan"), dtype=torch.bfloat16, device=dev)
+  native.run_op("conv", g.fwd(x.data_ptr(), _pack(native, g, w, "fwd").data_ptr(), out.data_ptr(),
+                              cfg=cfg))
+  torch.cuda.synchronize()
+  ref = _ref_conv(x.float(), wq, stride, pad)
+  assert (out.float()[..., :Cout] - ref).abs().max().item() <= 0.02 * ref.abs().max().item() + 1e-2
+  dy = _bf(torch.randn(N, g.OH, g.OW, Cout, generator=gen)).to(dev)
+  xr = x.float().requires_grad_(True)
+  _ref_conv(xr, wq, stride, pad).backward(dy.float())
+  wd = _pack(native, g, w, "dgrad")
+  dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=dev)
+  for d in g.dgrad(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), cfg=cfg):
+    native.run_op("conv", d)
+  torch.cuda.synchronize()
+  assert (dx.float() - xr.grad).abs().max().item() <= 0.02 * xr.grad.abs().max().item() + 1e-2
 
 
 def test_conv_mfma_layout_identity():
@@ -236,7 +268,8 @@ def test_batchnorm_fwd_bwd(C, relu, residual, use_mask):
   saved = torch.zeros(4 * C, device=dev)
   ws = torch.zeros(native.ext().bn_workspace_floats(), device=dev)
   z = torch.empty(P, C, dtype=torch.bfloat16, device=dev)
-  mask = torch.full((P * C // 8,), 0xAA, dtype=torch.uint8, device=dev) if use_mask else None
+  mask = torch.full(((P * C // 8 + 3) // 4 * 4,), 0xAA, dtype=torch.uint8, device=dev) \
+      if use_mask else None
   native.run_op("bn_fwd_train", dict(
       y=y.data_ptr(), res=res.data_ptr() if residual else None, z=z.data_ptr(),
       mask=mask.data_ptr() if use_mask else None,
@@ -275,7 +308,7 @@ def test_batchnorm_fwd_bwd(C, relu, residual, use_mask):
   if use_mask:    # bit c of byte [row][chunk] <=> z[row, chunk*8 + c] > 0
     bits = (zq > 0).view(P, C // 8, 8).to(torch.int32)
     expect = (bits << torch.arange(8, device=dev)).sum(-1).to(torch.uint8)
-    assert torch.equal(mask.view(P, C // 8), expect)
+    assert torch.equal(mask[:P * C // 8].view(P, C // 8), expect)
   native.run_op("bn_bwd", dict(dz=dz.data_ptr(), y=y.data_ptr(),
                                z=z.data_ptr() if relu and not use_mask else None,
                                mask=mask.data_ptr() if use_mask else None,
