@@ -93,9 +93,15 @@ def _wgrad_candidates(desc: Dict) -> List[Tuple[int, int]]:
     seen = set()
     for target in (192, 256, 384, 512, 768, 1024, 1536):
       s = max(1, min(-(-target // tiles), max_splits))
-      if s not in seen:
-        seen.add(s)
-        out.append((c, s))
+      if s in seen:
+        continue
+      seen.add(s)
+      out.append((c, s))
+      # 2 / 4 wave groups per block share one atomic epilogue: same resident waves with
+      # half / a quarter of the blocks (cfg + 8 * log2(groups))
+      for lg, g in ((1, 2), (2, 4)):
+        if s >= g and (c + 8 * lg, -(-s // g)) not in out:
+          out.append((c + 8 * lg, -(-s // g)))
   return out
 
 

@@ -101,6 +101,7 @@ WgradParams wgrad_from_dict(const py::dict& d) {
   p.TJpad = get_or<int>(d, "TJpad", p.TJ);
   p.TJreal = get_or<int>(d, "TJreal", p.TJpad);
   p.splits = get_or<int>(d, "splits", 1);
+  p.debug_plain_store = get_or<int>(d, "debug_plain_store", 0);
   int pps = (p.P + p.splits - 1) / p.splits;
   pps = ((pps + 31) / 32) * 32;
   p.pix_per_split = pps;

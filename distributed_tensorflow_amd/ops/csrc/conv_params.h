@@ -41,6 +41,7 @@ struct WgradParams {
   // epilogue decode of the padded k index into the real HWIO index
   int Cpad = 0, Creal = 0, TJpad = 1, TJreal = 1;
   int splits = 1, pix_per_split = 0;
+  int debug_plain_store = 0;       // timing experiments only: plain stores instead of atomics
   FastDiv divOW, divOH, divCpad, divTJpad;
 };
 

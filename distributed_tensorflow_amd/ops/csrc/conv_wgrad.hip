@@ -16,6 +16,12 @@
 // MFMA operand.  The 32-byte column chunks of every LDS row are XOR-swizzled with a
 // function of the row so that the 8 rows touched by one 32-lane half fall into 8
 // distinct bank groups.
+//
+// The atomic epilogue is expensive (an fp32 tile per block and split: measured 25-45 % of the
+// kernel with 20-90 splits), so a block can hold G groups of four waves that work on
+// interleaved reduction steps of the same dW tile with their own LDS buffers, and add their
+// accumulators through LDS before one group issues the atomics: G times fewer atomic bytes
+// at the same number of resident waves.
 #include <stdexcept>
 #include <string>
 
@@ -61,8 +67,8 @@ __device__ __forceinline__ bf16x8 read_tr_frag(const uint8_t* tile, int c0, int 
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int BKK, int BCO, int WAVES_K, int WAVES_C, bool POINTWISE>
-__global__ __launch_bounds__(256, 4) void conv_wgrad_kernel(const WgradParams p) {
+template <int BKK, int BCO, int WAVES_K, int WAVES_C, int G, bool POINTWISE>
+__global__ __launch_bounds__(256 * G, 4) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int WKK = BKK / WAVES_K, WCO = BCO / WAVES_C;
   constexpr int KR = WKK / 16, CR = WCO / 16;
   constexpr int XCPR = BKK / 8, YCPR = BCO / 8;                 // 16-byte chunks per tile row
@@ -72,10 +78,15 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_kernel(const WgradParams p)
   static_assert(WAVES_K * WAVES_C == 4, "4 waves per block");
   static_assert(WKK % 16 == 0 && WCO % 16 == 0, "tile shape");
 
-  __shared__ __attribute__((aligned(16))) uint8_t smem[2 * (XBYTES + YBYTES)];
+  constexpr int GBYTES = 2 * (XBYTES + YBYTES);                 // LDS of one group
+  static_assert(G == 1 || BKK * BCO * 4 <= G * GBYTES, "accumulator exchange must fit in LDS");
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) uint8_t smem_all[G * GBYTES];
+
+  const int grp = threadIdx.x >> 8;                 // group of four waves
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;   // group-local ids
   const int wk = wave / WAVES_C, wc = wave % WAVES_C;
+  uint8_t* smem = smem_all + grp * GBYTES;
 
   const int tilesC = (p.Cout + BCO - 1) / BCO;
   const int kt = blockIdx.x / tilesC, ct = blockIdx.x % tilesC;
@@ -159,13 +170,15 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
     for (int b = 0; b < CR; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nsteps = (pend - pbeg + BP - 1) / BP;
-  issue_tile(pbeg, 0);
+  // group g takes reduction steps g, g + G, ...; the trip count is the same for every group
+  // (a step past the end loads zeros) because all of them meet at the block barrier
+  const int nsteps = ((pend - pbeg + BP - 1) / BP + G - 1) / G;
+  issue_tile(pbeg + grp * BP, 0);
   __syncthreads();                                  // includes the vmcnt(0) wait for the DMA
 
   for (int s = 0; s < nsteps; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nsteps) issue_tile(pbeg + (s + 1) * BP, buf ^ 1);
+    if (s + 1 < nsteps) issue_tile(pbeg + ((s + 1) * G + grp) * BP, buf ^ 1);
     const uint8_t* xs = smem + buf * (XBYTES + YBYTES);
     const uint8_t* ys = xs + XBYTES;
     bf16x8 xf[KR], yf[CR];
@@ -179,6 +192,32 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_kernel(const WgradParams p)
       for (int b = 0; b < CR; ++b)
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], yf[b], acc[a][b], 0, 0, 0);
     __syncthreads();
+  }
+
+  // ---- groups 1..G-1 hand their accumulators to group 0 through LDS ------------------------
+  if constexpr (G > 1) {
+    float* red = reinterpret_cast<float*>(smem_all);
+    for (int r = 1; r < G; ++r) {
+      if (grp == r) {
+#pragma unroll
+        for (int a = 0; a < KR; ++a)
+#pragma unroll
+          for (int b = 0; b < CR; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[((a * CR + b) * 4 + e) * 256 + tid] = acc[a][b][e];
+      }
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll
+        for (int a = 0; a < KR; ++a)
+#pragma unroll
+          for (int b = 0; b < CR; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[a][b][e] += red[((a * CR + b) * 4 + e) * 256 + tid];
+      }
+      __syncthreads();
+    }
+    if (grp != 0) return;
   }
 
   // ---- epilogue: atomic accumulation into the HWIO fp32 gradient ------------------------------
@@ -199,25 +238,38 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
       for (int b = 0; b < CR; ++b) {
         const int co = c0 + wc * WCO + b * 16 + fr;
-        if (co < p.Cout) atomicAdd(row + co, acc[a][b][r]);
+        if (co < p.Cout) {
+          if (p.debug_plain_store) row[co] = acc[a][b][r];
+          else atomicAdd(row + co, acc[a][b][r]);
+        }
       }
     }
   }
 }
 
-template <int BKK, int BCO, int WAVES_K, int WAVES_C>
-void launch_cfg(const WgradParams& p, hipStream_t stream) {
+template <int BKK, int BCO, int WAVES_K, int WAVES_C, int G>
+void launch_grp(const WgradParams& p, hipStream_t stream) {
   const int tilesK = (p.Ktotal + BKK - 1) / BKK;
   const int tilesC = (p.Cout + BCO - 1) / BCO;
   const bool pointwise = p.TI == 1 && p.TJ == 1 && p.ISH == 1 && p.ISW == 1 && p.dh0 == 0 &&
                          p.dw0 == 0 && p.OH == p.H && p.OW == p.W && p.Ctap <= p.Cpix;
   dim3 grid(tilesK * tilesC, p.splits);
   if (pointwise)
-    hipLaunchKernelGGL((conv_wgrad_kernel<BKK, BCO, WAVES_K, WAVES_C, true>), grid, dim3(256), 0,
-                       stream, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<BKK, BCO, WAVES_K, WAVES_C, G, true>), grid,
+                       dim3(256 * G), 0, stream, p);
   else
-    hipLaunchKernelGGL((conv_wgrad_kernel<BKK, BCO, WAVES_K, WAVES_C, false>), grid, dim3(256), 0,
-                       stream, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<BKK, BCO, WAVES_K, WAVES_C, G, false>), grid,
+                       dim3(256 * G), 0, stream, p);
+}
+
+template <int BKK, int BCO, int WAVES_K, int WAVES_C>
+void launch_cfg(const WgradParams& p, int groups, hipStream_t stream) {
+  switch (groups) {
+    case 1: launch_grp<BKK, BCO, WAVES_K, WAVES_C, 1>(p, stream); break;
+    case 2: launch_grp<BKK, BCO, WAVES_K, WAVES_C, 2>(p, stream); break;
+    case 4: launch_grp<BKK, BCO, WAVES_K, WAVES_C, 4>(p, stream); break;
+    default: throw std::invalid_argument("conv_wgrad: groups must be 1, 2 or 4");
+  }
 }
 
 }  // namespace
@@ -245,17 +297,20 @@ void validate_wgrad_params(const WgradParams& p) {
   }
 }
 
+// cfg = tile id (0..7) + 8 * log2(groups): 0..7 one group of four waves per block, 8..15 two
+// groups, 16..23 four groups.
 void launch_conv_wgrad(const WgradParams& p, int cfg, hipStream_t stream) {
   validate_wgrad_params(p);
-  switch (cfg) {
-    case 0: launch_cfg<128, 128, 2, 2>(p, stream); break;
-    case 1: launch_cfg<128, 64, 2, 2>(p, stream); break;
-    case 2: launch_cfg<64, 128, 2, 2>(p, stream); break;
-    case 3: launch_cfg<64, 64, 2, 2>(p, stream); break;
-    case 4: launch_cfg<128, 32, 4, 1>(p, stream); break;
-    case 5: launch_cfg<128, 16, 4, 1>(p, stream); break;
-    case 6: launch_cfg<32, 32, 2, 2>(p, stream); break;
-    case 7: launch_cfg<64, 16, 4, 1>(p, stream); break;
-    default: throw std::invalid_argument("conv_wgrad: unknown tile config");
+  if (cfg < 0 || cfg >= 24) throw std::invalid_argument("conv_wgrad: unknown tile config");
+  const int g = 1 << (cfg / 8);
+  switch (cfg % 8) {
+    case 0: launch_cfg<128, 128, 2, 2>(p, g, stream); break;
+    case 1: launch_cfg<128, 64, 2, 2>(p, g, stream); break;
+    case 2: launch_cfg<64, 128, 2, 2>(p, g, stream); break;
+    case 3: launch_cfg<64, 64, 2, 2>(p, g, stream); break;
+    case 4: launch_cfg<128, 32, 4, 1>(p, g, stream); break;
+    case 5: launch_cfg<128, 16, 4, 1>(p, g, stream); break;
+    case 6: launch_cfg<32, 32, 2, 2>(p, g, stream); break;
+    case 7: launch_cfg<64, 16, 4, 1>(p, g, stream); break;
   }
 }

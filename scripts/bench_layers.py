@@ -77,6 +77,7 @@ def main():
     wgd = g.wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr())
     if "wgrad" in overrides: wgd["cfg"] = overrides["wgrad"]
     if "splits" in overrides: wgd["splits"] = overrides["splits"]
+    if os.environ.get("DTF_WGRAD_PLAIN") == "1": wgd["debug_plain_store"] = 1
     t_w = timeit(lambda: native.run_op("wgrad", wgd))
     n = len(names)
     rf = max(2 * macs / PEAK_TF / 1e6, bytes_f / PEAK_GBS / 1e3)

@@ -179,6 +179,28 @@ def test_conv_every_tile_config(cfg, shape):
   assert (dx.float() - xr.grad).abs().max().item() <= 0.02 * xr.grad.abs().max().item() + 1e-2
 
 
+@pytest.mark.parametrize("cfg,splits", [(0, 5), (8, 3), (16, 2), (10, 4), (19, 1), (9, 7), (20, 2),
+                                        (14, 3), (23, 2)])
+@pytest.mark.parametrize("shape", [(3, 19, 19, 64, 3, 136, 2), (2, 15, 15, 96, 1, 72, 1)])
+def test_wgrad_every_tile_config_and_group_count(cfg, splits, shape):
+  """Weight gradient under every tile / wave-group combination (cfg = tile + 8*log2(groups))."""
+  native = _native()
+  N, H, W, Cin, K, Cout, stride = shape
+  dev = torch.device("cuda")
+  gen = torch.Generator(device="cpu").manual_seed(cfg + H)
+  pad = same_padding(H, K, stride) + same_padding(W, K, stride)
+  g = ConvGeom(N, H, W, Cin, K, K, Cout, stride, pad)
+  x = _bf(torch.randn(N, H, W, Cin, generator=gen)).to(dev)
+  dy = _bf(torch.randn(N, g.OH, g.OW, Cout, generator=gen)).to(dev)
+  wr = torch.zeros(K, K, Cin, Cout, device=dev).requires_grad_(True)
+  _ref_conv(x.float(), wr, stride, pad).backward(dy.float())
+  dw = torch.zeros(K, K, Cin, Cout, dtype=torch.float32, device=dev)
+  native.run_op("wgrad", g.wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), cfg=cfg,
+                                 splits=splits))
+  torch.cuda.synchronize()
+  assert (dw - wr.grad).abs().max().item() <= 0.01 * wr.grad.abs().max().item() + 1e-2
+
+
 def test_conv_mfma_layout_identity():
   """A = I with an asymmetric B: catches a transposed / permuted accumulator mapping."""
   native = _native()
