@@ -331,6 +331,9 @@ class HipExecutor:
     grads: Dict[str, torch.Tensor] = {spec.logits_name: self.dlogits}
     written = {spec.logits_name}
     self.act_grads = grads
+    # tensor name -> (dz tensor, mask address): a gradient contribution dz * mask that has not
+    # been written anywhere yet
+    pending: Dict[str, Tuple[torch.Tensor, Optional[int]]] = {}
 
     def grad_buf(name: str) -> torch.Tensor:
       if name not in grads:
@@ -366,8 +369,10 @@ class HipExecutor:
     for op in reversed(spec.ops):
       at = op.attrs
       xname = op.inputs[0]
-      dout = grads.get(op.output)
-      if dout is None:
+      dout = grads.get(op.output) if op.output in written else None
+      if dout is None and op.output in pending and op.kind != "bn":
+        dout = self._materialize_pending(plan, op.output, pending, grad_buf, written)
+      if dout is None and op.output not in pending:
         raise RuntimeError("no gradient reaches %s" % op.output)
       if op.kind == "dense":
         g = self.geoms[op.name]
@@ -409,20 +414,23 @@ class HipExecutor:
         if xname in written:
           raise RuntimeError("BatchNorm input with several consumers is not planned")
         dy = grad_buf(xname)
-        dres = None
+        dz_ptr, mask_ptr = self._bn_incoming_grad(plan, op, dout, pending)
         if len(op.inputs) > 1:
+          # The gradient of the residual branch is dz gated by this layer's ReLU mask.  It is
+          # not written out: whoever consumes it (the data gradient of the block's first
+          # convolution, or the BatchNorm of a projection shortcut) reads dz and the mask.
           rname = op.inputs[1]
-          if rname in written:
+          if rname in written or rname in pending:
             raise RuntimeError("residual gradient must be the first writer of %s" % rname)
-          dres = grad_buf(rname).data_ptr()
-          written.add(rname)
+          if dout is None:
+            raise RuntimeError("residual BatchNorm %s fed by a deferred gradient" % op.name)
+          pending[rname] = (dout, mask_ptr)
         plan.add("bn_bwd", dict(
-            dz=dout.data_ptr(), y=x.data_ptr(),
-            z=None, mask=self._bn_mask[op.name].data_ptr() if at["relu"] else None,
+            dz=dz_ptr, y=x.data_ptr(), z=None, mask=mask_ptr,
             mean=mean_p, invstd=inv_p,
             gamma=self._var_ptr(op.name + "/gamma"),
             dgamma=self._var_ptr(op.name + "/gamma", "grad"),
-            dbeta=self._var_ptr(op.name + "/beta", "grad"), dy=dy.data_ptr(), dres=dres,
+            dbeta=self._var_ptr(op.name + "/beta", "grad"), dy=dy.data_ptr(), dres=None,
             ws=self.bn_ws.data_ptr(), P=P, C=C), op.name + "/bwd")
         written.add(xname)
         done([op.name + "/gamma", op.name + "/beta"])
@@ -432,8 +440,14 @@ class HipExecutor:
                                   self._var_ptr(op.name + "/kernel", "grad")), op.name + "/wgrad")
         if op is not first_conv:
           dx = grad_buf(xname)
+          add, add_mask = None, None
+          if xname in pending and xname not in written and g.Cin % 8 == 0:
+            pt, pm = pending.pop(xname)
+            add, add_mask = pt.data_ptr(), pm
+          elif xname in pending:
+            self._materialize_pending(plan, xname, pending, grad_buf, written)
           for d in g.dgrad(dout.data_ptr(), self._wd_ptr(op.name), dx.data_ptr(),
-                           accumulate=xname in written):
+                           accumulate=xname in written, addend=add, addend_mask=add_mask):
             self._add(plan, "conv", d, op.name + "/dgrad")
           written.add(xname)
         done([op.name + "/kernel"])
@@ -442,6 +456,32 @@ class HipExecutor:
     left = [i for i, r in remaining.items() if r]
     if left:
       raise RuntimeError("buckets never completed: %s" % left)
+
+  def _materialize_pending(self, plan, name: str, pending, grad_buf, written) -> torch.Tensor:
+    """Writes a deferred `dz * mask` gradient into the gradient buffer of `name`."""
+    if name in written:
+      raise RuntimeError("deferred residual gradient of %s would overwrite a written one" % name)
+    src, mask = pending.pop(name)
+    dst = grad_buf(name)
+    if mask is None:
+      raise RuntimeError("unmasked deferred gradient for %s" % name)
+    plan.add("mask_apply", dict(x=src.data_ptr(), mask=mask, out=dst.data_ptr(), n=dst.numel()),
+             name + "/residual_grad")
+    written.add(name)
+    return dst
+
+  def _bn_incoming_grad(self, plan, op: Op, dout, pending) -> Tuple[int, Optional[int]]:
+    """(dz address, ReLU-mask address) for the backward of BatchNorm `op`.
+
+    When the gradient of the output is a deferred `dz * mask` (this BatchNorm normalises a
+    projection shortcut) the incoming mask is used in place of an own one."""
+    own = self._bn_mask[op.name].data_ptr() if op.attrs["relu"] else None
+    if dout is not None:
+      return dout.data_ptr(), own
+    src, mask = pending.pop(op.output)
+    if own is not None:
+      raise RuntimeError("BatchNorm %s has its own ReLU and a deferred masked gradient" % op.name)
+    return src.data_ptr(), mask
 
   # ----------------------------------------------------------------------------------------
   # execution

@@ -22,7 +22,7 @@ from . import conv_plan
 __all__ = ["signature", "lookup", "apply", "tune", "save", "enabled", "CACHE_PATH"]
 
 CACHE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
-_POINTERS = ("in", "wgt", "out", "addend", "bias", "stats", "x", "dy", "dw")
+_POINTERS = ("in", "wgt", "out", "addend", "addend_mask", "bias", "stats", "x", "dy", "dw")
 _IGNORED = _POINTERS + ("cfg", "splits", "stats_replicas")
 _cache: Optional[Dict[str, Dict[str, int]]] = None
 _dirty = False
@@ -50,7 +50,7 @@ def signature(kind: str, desc: Dict) -> str:
     if k in _IGNORED:
       continue
     parts.append("%s=%s" % (k, desc[k]))
-  for k in ("addend", "bias", "stats"):
+  for k in ("addend", "addend_mask", "bias", "stats"):
     if desc.get(k) is not None:
       parts.append("+" + k)
   return "|".join(parts)

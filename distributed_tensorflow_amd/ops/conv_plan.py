@@ -165,8 +165,12 @@ class ConvGeom:
 
   # -- data gradient ------------------------------------------------------------------------
   def dgrad(self, dy: int, wd: int, dx: int, accumulate: bool = False,
-            cfg: Optional[int] = None) -> List[Dict]:
-    """dX[N,H,W,Cin] from dY[N,OH,OW,ldc]; `accumulate` adds to the existing dX."""
+            cfg: Optional[int] = None, addend: Optional[int] = None,
+            addend_mask: Optional[int] = None) -> List[Dict]:
+    """dX[N,H,W,Cin] from dY[N,OH,OW,ldc]; `accumulate` adds to the existing dX, `addend`
+    (a tensor shaped like dX, optionally gated by the 1-bit `addend_mask`) is added instead."""
+    if accumulate and addend is not None:
+      raise ValueError("either accumulate into dX or add another tensor")
     if self.mode != "normal" or self.Cin % 8:
       raise ValueError("data gradient needs a normal-mode convolution with Cin % 8 == 0")
     if self.ldc != self.cout_pad:
@@ -198,7 +202,9 @@ class ConvGeom:
         d["in"] = dy
         d["wgt"] = wd
         d["out"] = dx
-        d["addend"] = dx if accumulate else None
+        d["addend"] = dx if accumulate else addend
+        if addend is not None and addend_mask is not None:
+          d["addend_mask"] = addend_mask
         out.append(d)
     return out
 

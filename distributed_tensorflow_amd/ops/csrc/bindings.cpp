@@ -52,6 +52,7 @@ ConvParams conv_from_dict(const py::dict& d) {
   p.wgt = ptr<const bf16_t>(d, "wgt");
   p.out = ptr<bf16_t>(d, "out");
   p.addend = ptr<const bf16_t>(d, "addend", false);
+  p.addend_mask = ptr<const uint8_t>(d, "addend_mask", false);
   p.bias = ptr<const float>(d, "bias", false);
   p.stats = ptr<float>(d, "stats", false);
   p.stats_replicas = get_or<int>(d, "stats_replicas", 0);
@@ -165,6 +166,12 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     return [=](hipStream_t s) {
       launch_bn_bwd(dz, y, z, mask, mean, inv, gamma, dgamma, dbeta, dy, dres, ws, P, C, s);
     };
+  }
+  if (kind == "mask_apply") {
+    auto x = ptr<const bf16_t>(d, "x"); auto mask = ptr<const uint8_t>(d, "mask");
+    auto out = ptr<bf16_t>(d, "out");
+    const size_t n = get<size_t>(d, "n");
+    return [=](hipStream_t s) { launch_mask_apply(x, mask, out, n, s); };
   }
   if (kind == "maxpool_fwd" || kind == "maxpool_bwd") {
     const int N = get<int>(d, "N"), H = get<int>(d, "H"), W = get<int>(d, "W"), C = get<int>(d, "C");

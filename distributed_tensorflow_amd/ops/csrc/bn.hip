@@ -346,6 +346,20 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   }
 }
 
+__global__ __launch_bounds__(TPB) void mask_apply_kernel(const bf16_t* __restrict__ x,
+                                                         const uint8_t* __restrict__ mask,
+                                                         bf16_t* __restrict__ out, size_t nvec) {
+  for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (size_t)gridDim.x * TPB) {
+    u32x4 v = *reinterpret_cast<const u32x4*>(x + i * 8);
+    const uint32_t b = mask[i];
+    v.x &= ((b & 1u) ? 0xffffu : 0u) | ((b & 2u) ? 0xffff0000u : 0u);
+    v.y &= ((b & 4u) ? 0xffffu : 0u) | ((b & 8u) ? 0xffff0000u : 0u);
+    v.z &= ((b & 16u) ? 0xffffu : 0u) | ((b & 32u) ? 0xffff0000u : 0u);
+    v.w &= ((b & 64u) ? 0xffffu : 0u) | ((b & 128u) ? 0xffff0000u : 0u);
+    *reinterpret_cast<u32x4*>(out + i * 8) = v;
+  }
+}
+
 void check_channels(int C, int P) {
   if (C < 8 || C > 2048 || (C & (C - 1)))
     throw std::invalid_argument("batch-norm kernels need a power-of-two channel count in [8, 2048]");
@@ -387,6 +401,15 @@ void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, uint8_t*
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 31) / 32), dim3(TPB), 0, s, f);
   BnApplyArgs a{y, res, z, mask, scale, shift, gamma, beta, mm, mv, P, C, eps, relu};
   hipLaunchKernelGGL(bn_apply_kernel, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
+}
+
+void launch_mask_apply(const bf16_t* x, const uint8_t* mask, bf16_t* out, size_t n, hipStream_t s) {
+  if (n % 8) throw std::invalid_argument("mask_apply: element count must be a multiple of 8");
+  const size_t nvec = n / 8;
+  if (nvec == 0) return;
+  const size_t blocks = (nvec + TPB - 1) / TPB;
+  hipLaunchKernelGGL(mask_apply_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(TPB), 0,
+                     s, x, mask, out, nvec);
 }
 
 void launch_bn_infer(const bf16_t* y, const bf16_t* res, bf16_t* z, const float* gamma,

@@ -325,19 +325,20 @@ void conv_igemm_kernel(const ConvParams p) {
   for (int mr = 0; mr < MR; ++mr) {
     const int m = m0 + wm * WM + mr * 16 + fr;
     if (m >= p.M) continue;
-    size_t obase;
+    size_t opix;                                   // linear pixel index in the output tensor
     if (POINTWISE) {
-      obase = (size_t)m * p.ldc;
+      opix = (size_t)m;
     } else {
       const uint32_t t = fd_div((uint32_t)m, p.divOW);
       const int ow = m - (int)t * p.OW;
       const uint32_t n = fd_div(t, p.divOH);
       const int oh = (int)t - (int)n * p.OH;
-      obase = ((size_t)((int)n * p.OHfull + oh * p.OSH + p.OOH) * p.OWfull +
-               (ow * p.OSW + p.OOW)) * p.ldc;
+      opix = (size_t)((int)n * p.OHfull + oh * p.OSH + p.OOH) * p.OWfull + (ow * p.OSW + p.OOW);
     }
+    const size_t obase = opix * p.ldc;
     bf16_t* optr = p.out + obase + co0;
     const bf16_t* aptr = p.addend ? p.addend + obase + co0 : nullptr;
+    const uint8_t* mptr = p.addend_mask ? p.addend_mask + opix * (p.ldc >> 3) + (co0 >> 3) : nullptr;
     if constexpr (CPL >= 8) {
 #pragma unroll
       for (int h = 0; h < CPL / 8; ++h) {
@@ -348,7 +349,14 @@ void conv_igemm_kernel(const ConvParams p) {
         float v6 = acc[2 * h + 1][mr][2] + bias[h * 8 + 6], v7 = acc[2 * h + 1][mr][3] + bias[h * 8 + 7];
         if (vec_ok && co0 + h * 8 + 8 <= p.Cout) {
           if (aptr) {
-            const u32x4 a = *reinterpret_cast<const u32x4*>(aptr + h * 8);
+            u32x4 a = *reinterpret_cast<const u32x4*>(aptr + h * 8);
+            if (mptr) {                            // keep only the elements whose mask bit is set
+              const uint32_t b = mptr[h];
+              a.x &= ((b & 1u) ? 0xffffu : 0u) | ((b & 2u) ? 0xffff0000u : 0u);
+              a.y &= ((b & 4u) ? 0xffffu : 0u) | ((b & 8u) ? 0xffff0000u : 0u);
+              a.z &= ((b & 16u) ? 0xffffu : 0u) | ((b & 32u) ? 0xffff0000u : 0u);
+              a.w &= ((b & 64u) ? 0xffffu : 0u) | ((b & 128u) ? 0xffff0000u : 0u);
+            }
             v0 += __uint_as_float(a.x << 16); v1 += __uint_as_float(a.x & 0xffff0000u);
             v2 += __uint_as_float(a.y << 16); v3 += __uint_as_float(a.y & 0xffff0000u);
             v4 += __uint_as_float(a.z << 16); v5 += __uint_as_float(a.z & 0xffff0000u);
@@ -386,7 +394,12 @@ void conv_igemm_kernel(const ConvParams p) {
       float v2 = acc[0][mr][2] + bias[2], v3 = acc[0][mr][3] + bias[3];
       if (p.ldc % 4 == 0 && co0 + 4 <= p.Cout) {
         if (aptr) {
-          const u32x2 a = *reinterpret_cast<const u32x2*>(aptr);
+          u32x2 a = *reinterpret_cast<const u32x2*>(aptr);
+          if (mptr) {                              // this lane's 4 channels: one nibble of the byte
+            const uint32_t b = (uint32_t)mptr[0] >> (co0 & 4);
+            a.x &= ((b & 1u) ? 0xffffu : 0u) | ((b & 2u) ? 0xffff0000u : 0u);
+            a.y &= ((b & 4u) ? 0xffffu : 0u) | ((b & 8u) ? 0xffff0000u : 0u);
+          }
           v0 += __uint_as_float(a.x << 16); v1 += __uint_as_float(a.x & 0xffff0000u);
           v2 += __uint_as_float(a.y << 16); v3 += __uint_as_float(a.y & 0xffff0000u);
         }
@@ -474,6 +487,10 @@ void validate_conv_params(const ConvParams& p) {
   if (p.TI * p.TJ > 0 && p.wk0 + (p.TI - 1) * p.wsi + (p.TJ - 1) * p.wsj + p.Ctap > p.ldw)
     fail("weight row overrun");
   if (p.Cout <= 0 || p.ldc < p.Cout) fail("ldc < Cout");
+  if (p.addend_mask) {
+    if (!p.addend) fail("addend_mask without addend");
+    if (p.Cout % 8 || p.ldc % 8) fail("a masked addend needs Cout and ldc to be multiples of 8");
+  }
   if (p.stats) {
     if (p.stats_replicas <= 0) fail("stats needs a positive replica count");
     if (p.bias || p.addend) fail("fused statistics need a plain convolution (no bias / addend)");

@@ -9,6 +9,9 @@ struct ConvParams {
   const bf16_t* wgt = nullptr;     // packed [Cout][ldw], K contiguous
   bf16_t* out = nullptr;           // [N, OHfull, OWfull, ldc]
   const bf16_t* addend = nullptr;  // optional tensor added to the result (same layout as out)
+  // optional 1-bit mask of the addend, [pixels][ldc/8] bytes in the layout of `out`: only
+  // elements whose bit is set are added (the ReLU mask of a residual branch's gradient)
+  const uint8_t* addend_mask = nullptr;
   const float* bias = nullptr;     // optional per-output-channel bias
   // optional fused batch-norm statistics: per-channel sum / sum of squares of the (bf16
   // rounded) output, added atomically into replica (m-tile % replicas) of

@@ -19,6 +19,10 @@ void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const uin
                    float* dbeta, bf16_t* dy, bf16_t* dres, float* ws, int P, int C,
                    hipStream_t s);
 
+// out[i] = bit (i % 8) of mask[i / 8] ? x[i] : 0, n a multiple of 8 (materialises a masked
+// gradient when its consumer cannot apply the mask itself).
+void launch_mask_apply(const bf16_t* x, const uint8_t* mask, bf16_t* out, size_t n, hipStream_t s);
+
 void launch_maxpool_fwd(const bf16_t* x, bf16_t* out, uint8_t* idx, int N, int H, int W, int C,
                         int OH, int OW, int k, int stride, int pt, int pl, hipStream_t s);
 void launch_maxpool_bwd(const bf16_t* dy, const uint8_t* idx, bf16_t* dx, int N, int H, int W,

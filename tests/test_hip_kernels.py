@@ -201,6 +201,40 @@ def test_wgrad_every_tile_config_and_group_count(cfg, splits, shape):
   assert (dw - wr.grad).abs().max().item() <= 0.01 * wr.grad.abs().max().item() + 1e-2
 
 
+@pytest.mark.parametrize("K,cfg,Cin", [(1, 0, 72), (3, 6, 72), (3, 5, 72), (3, 3, 16), (3, 2, 24),
+                                       (1, 3, 8)])
+def test_dgrad_masked_addend_and_mask_apply(K, cfg, Cin):
+  """dX = dgrad(dY) + addend * bitmask (the deferred residual gradient), and the stand-alone
+  mask kernel."""
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator(device="cpu").manual_seed(K)
+  N, H, Cout = 3, 13, 64
+  pad = same_padding(H, K, 1) + same_padding(H, K, 1)
+  g = ConvGeom(N, H, H, Cin, K, K, Cout, 1, pad)
+  w = (torch.randn(K, K, Cin, Cout, generator=gen) * 0.1).to(dev)
+  dy = _bf(torch.randn(N, H, H, Cout, generator=gen)).to(dev)
+  add = _bf(torch.randn(N, H, H, Cin, generator=gen)).to(dev)
+  keep = torch.rand(N, H, H, Cin, generator=gen).to(dev) > 0.4
+  bits = (keep.view(-1, Cin // 8, 8).to(torch.int32) << torch.arange(8, device=dev)).sum(-1)
+  mask = bits.to(torch.uint8).contiguous()
+  xr = torch.zeros(N, H, H, Cin, device=dev).requires_grad_(True)
+  _ref_conv(xr, _bf(w).float(), 1, pad).backward(dy.float())
+  ref = xr.grad + add.float() * keep
+  dx = torch.full((N, H, H, Cin), float("nan"), dtype=torch.bfloat16, device=dev)
+  wd = _pack(native, g, w, "dgrad")
+  for d in g.dgrad(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), cfg=cfg, addend=add.data_ptr(),
+                   addend_mask=mask.data_ptr()):
+    native.run_op("conv", d)
+  torch.cuda.synchronize()
+  assert (dx.float() - ref).abs().max().item() <= 0.02 * ref.abs().max().item() + 2e-2
+  out = torch.empty_like(add)
+  native.run_op("mask_apply", dict(x=add.data_ptr(), mask=mask.data_ptr(), out=out.data_ptr(),
+                                   n=add.numel()))
+  torch.cuda.synchronize()
+  assert torch.equal(out.float(), add.float() * keep)
+
+
 def test_conv_mfma_layout_identity():
   """A = I with an asymmetric B: catches a transposed / permuted accumulator mapping."""
   native = _native()
