@@ -131,11 +131,13 @@ def main() -> int:
   if rank == 0:
     value = global_batch * a.steps / dt
     out = {
-        "metric": "images/sec (whole node) ResNet-50 ImageNet-224 bs256/GPU",
+        "metric": ("images/sec (whole node) ResNet-50 ImageNet-224 bs256/GPU" if a.model == "resnet50"
+                   else "images/sec (whole node) ResNet-56 CIFAR-10 bs%d/GPU" % a.batch),
         "value": round(value, 2), "unit": "images/sec", "n_gpus": a.gpus, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1000.0 * dt / a.steps, 3),
         "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": round(value / baseline_for(a.gpus), 3), "dtype": "bf16",
+        "vs_baseline": round(value / baseline_for(a.gpus), 3) if a.model == "resnet50" else None,
+        "dtype": "bf16",
         "data": "synthetic (device-resident batch), random-init weights",
         "config": {"model": "resnet50_v1.5" if a.model == "resnet50" else a.model,
                    "global_batch": global_batch, "per_gpu_batch": a.batch,

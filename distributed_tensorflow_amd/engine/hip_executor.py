@@ -237,7 +237,7 @@ class HipExecutor:
     blk = 0
     for d in descs:
       d["first_block"] = blk
-      blk += -(-d["count"] // native.PACK_PER_BLOCK)
+      blk += native.pack_blocks(d)
     self.packed = self._alloc((off,), torch.bfloat16)
     raw = native.pack_desc_bytes(descs)
     self.pack_descs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)

@@ -107,28 +107,31 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const bf16_t* __restrict_
   block_reduce_to_partials<16>(part, tpr, chunk, rowid, ws + (size_t)blockIdx.x * 2 * C, C);
 }
 
-// Sums the G partial rows of the workspace: column j of [G][cols]. 32 columns per block,
-// 8 row lanes per column; 8 independent loads in flight per thread (the loop is latency bound).
+// Sums the G partial rows of the workspace: column j of [G][cols].  A finalize block has 1024
+// threads = 32 columns x 32 row lanes (the loop is latency bound: a thread walks G/32 rows with
+// 8 independent loads in flight).
+constexpr int FIN_TPB = 1024, FIN_RL = FIN_TPB / 32;
+
 __device__ __forceinline__ float column_sum(const float* __restrict__ ws, int G, int cols, int col,
                                             int rl, float* red) {
   float s = 0.f;
   if (col < cols) {
     const float* p = ws + col;
     int g = rl;
-    for (; g + 56 < G; g += 64) {
+    for (; g + 7 * FIN_RL < G; g += 8 * FIN_RL) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(g + 8 * u) * cols];
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(g + FIN_RL * u) * cols];
       s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
-    for (; g < G; g += 8) s += p[(size_t)g * cols];
+    for (; g < G; g += FIN_RL) s += p[(size_t)g * cols];
   }
   red[rl * 32 + (threadIdx.x & 31)] = s;
   __syncthreads();
   float t = 0.f;
   if (rl == 0) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) t += red[r * 32 + (threadIdx.x & 31)];
+    for (int r = 0; r < FIN_RL; ++r) t += red[r * 32 + (threadIdx.x & 31)];
   }
   __syncthreads();
   return t;
@@ -143,8 +146,8 @@ struct BnFinalizeArgs {
 
 // One block per 32 channels: mean / variance from the partial sums, scale / shift for the
 // apply sweep, saved statistics for backward, moving-average update.
-__global__ __launch_bounds__(TPB) void bn_fwd_finalize_kernel(const BnFinalizeArgs a) {
-  __shared__ float red[256];
+__global__ __launch_bounds__(FIN_TPB) void bn_fwd_finalize_kernel(const BnFinalizeArgs a) {
+  __shared__ float red[FIN_TPB];
   const int ch = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
   const float s1 = column_sum(a.ws, a.G, 2 * a.C, ch, rl, red);
   const float s2 = column_sum(a.ws, a.G, 2 * a.C, a.C + ch, rl, red);
@@ -295,8 +298,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
   block_reduce_to_partials<16>(part, tpr, chunk, rowid, a.ws + (size_t)blockIdx.x * 2 * C, C);
 }
 
-__global__ __launch_bounds__(TPB) void bn_bwd_finalize_kernel(const BnBwdArgs a) {
-  __shared__ float red[256];
+__global__ __launch_bounds__(FIN_TPB) void bn_bwd_finalize_kernel(const BnBwdArgs a) {
+  __shared__ float red[FIN_TPB];
   const int ch = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
   const float dg = column_sum(a.ws, a.G, 2 * a.C, ch, rl, red);
   const float db = column_sum(a.ws, a.G, 2 * a.C, a.C + ch, rl, red);
@@ -320,18 +323,17 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
     c1[c] = a.dbeta[ch] * invP;
     c2[c] = a.dgamma[ch] * invP;
   }
-  for (int row = blockIdx.x * rpb + rowid; row < a.P; row += gridDim.x * rpb) {
-    const size_t off = (size_t)row * C + chunk * 8;
+  const int mode = a.mask ? 2 : (a.z ? 1 : 0);
+  auto finish = [&](const u32x4& gv, const u32x4& yq, const u32x4& zq, uint32_t bits, size_t off) {
     float g[8], yv[8];
-    unpack8(*reinterpret_cast<const u32x4*>(a.dz + off), g);
-    unpack8(*reinterpret_cast<const u32x4*>(a.y + off), yv);
-    if (a.mask) {
-      const uint32_t bits = a.mask[(size_t)row * tpr + chunk];
+    unpack8(gv, g);
+    unpack8(yq, yv);
+    if (mode == 2) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) g[c] = (bits >> c) & 1u ? g[c] : 0.f;
-    } else if (a.z) {
+    } else if (mode == 1) {
       float zv[8];
-      unpack8(*reinterpret_cast<const u32x4*>(a.z + off), zv);
+      unpack8(zq, zv);
 #pragma unroll
       for (int c = 0; c < 8; ++c) g[c] = zv[c] > 0.f ? g[c] : 0.f;
     }
@@ -343,6 +345,31 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
       o[c] = scale[c] * (g[c] - c1[c] - xhat * c2[c]);
     }
     *reinterpret_cast<u32x4*>(a.dy + off) = pack8(o);
+  };
+  const int stride = gridDim.x * rpb;
+  int row = blockIdx.x * rpb + rowid;
+  for (; row + stride < a.P; row += 2 * stride) {          // two rows of loads in flight
+    u32x4 gv[2], yq[2], zq[2];
+    uint32_t bits[2];
+    size_t off[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      off[u] = (size_t)(row + u * stride) * C + chunk * 8;
+      gv[u] = *reinterpret_cast<const u32x4*>(a.dz + off[u]);
+      yq[u] = *reinterpret_cast<const u32x4*>(a.y + off[u]);
+      zq[u] = mode == 1 ? *reinterpret_cast<const u32x4*>(a.z + off[u]) : u32x4{0, 0, 0, 0};
+      bits[u] = mode == 2 ? a.mask[(size_t)(row + u * stride) * tpr + chunk] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) finish(gv[u], yq[u], zq[u], bits[u], off[u]);
+  }
+  for (; row < a.P; row += stride) {
+    const size_t off = (size_t)row * C + chunk * 8;
+    const u32x4 gv = *reinterpret_cast<const u32x4*>(a.dz + off);
+    const u32x4 yq = *reinterpret_cast<const u32x4*>(a.y + off);
+    const u32x4 zq = mode == 1 ? *reinterpret_cast<const u32x4*>(a.z + off) : u32x4{0, 0, 0, 0};
+    const uint32_t bits = mode == 2 ? a.mask[(size_t)row * tpr + chunk] : 0u;
+    finish(gv, yq, zq, bits, off);
   }
 }
 
@@ -398,7 +425,7 @@ void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, uint8_t*
   }
   BnFinalizeArgs f{ws, G, gamma, beta, mm, mv, save_mean, save_invstd, scale, shift,
                    P, C, eps, momentum};
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 31) / 32), dim3(TPB), 0, s, f);
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, f);
   BnApplyArgs a{y, res, z, mask, scale, shift, gamma, beta, mm, mv, P, C, eps, relu};
   hipLaunchKernelGGL(bn_apply_kernel, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
 }
@@ -428,6 +455,6 @@ void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const uin
   const int G = reduce_grid(P, C);
   BnBwdArgs a{dz, y, z, mask, mean, invstd, gamma, dgamma, dbeta, dy, dres, ws, G, P, C};
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(G), dim3(TPB), 0, s, a);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(TPB), 0, s, a);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, a);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
 }

@@ -75,32 +75,54 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     if (descs[mid].first_block <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const PackDesc d = descs[lo];
-  const int64_t base = ((int64_t)blockIdx.x - d.first_block) * PACK_PER_BLOCK;
   const float* src = params + d.src_off;
   bf16_t* dst = packed + d.dst_off;
+  if (d.mode == 0) {
+    // dst[co][ti][tjp][cp] from src[ti][tj][ci][co]: a transpose between the two innermost
+    // dimensions.  One block moves a tile of 32 cp x 64 co of one tap through LDS so that both
+    // the fp32 reads (co contiguous) and the bf16 writes (cp contiguous) are coalesced.
+    __shared__ float tile[32][65];
+    int64_t b = (int64_t)blockIdx.x - d.first_block;
+    const int cot = (d.Cout + 63) / 64, cpt = (d.Cpad + 31) / 32;
+    const int co0 = (int)(b % cot) * 64; b /= cot;
+    const int cp0 = (int)(b % cpt) * 32; b /= cpt;
+    const int tjp = (int)(b % d.TJpad);
+    const int ti = (int)(b / d.TJpad);
+    {
+      const int co = co0 + (threadIdx.x & 63);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = (threadIdx.x >> 6) + 4 * k, cp = cp0 + r;
+        float v = 0.f;
+        if (cp < d.Cin && tjp < d.TJ && co < d.Cout)
+          v = src[((int64_t)(ti * d.TJ + tjp) * d.Cin + cp) * d.Cout + co];
+        tile[r][threadIdx.x & 63] = v;
+      }
+    }
+    __syncthreads();
+    {
+      const int r = threadIdx.x & 31, cp = cp0 + r;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = (threadIdx.x >> 5) + 8 * k, co = co0 + c;
+        if (cp < d.Cpad && co < d.Cout)
+          dst[(((int64_t)co * d.TI + ti) * d.TJpad + tjp) * d.Cpad + cp] = f2bf(tile[r][c]);
+      }
+    }
+    return;
+  }
+  // mode 1: dst[ci][ti][tj][cop], cop contiguous in both tensors
+  const int64_t base = ((int64_t)blockIdx.x - d.first_block) * PACK_PER_BLOCK;
   for (int e = 0; e < 8; ++e) {
     const int64_t i = base + e * 256 + threadIdx.x;
     if (i >= d.count) return;
+    int64_t r = i;
+    const int cop = (int)(r % d.CoutPad); r /= d.CoutPad;
+    const int tj = (int)(r % d.TJ); r /= d.TJ;
+    const int ti = (int)(r % d.TI);
+    const int ci = (int)(r / d.TI);
     float val = 0.f;
-    if (d.mode == 0) {
-      // dst[co][ti][tjp][cp]
-      int64_t r = i;
-      const int cp = (int)(r % d.Cpad); r /= d.Cpad;
-      const int tjp = (int)(r % d.TJpad); r /= d.TJpad;
-      const int ti = (int)(r % d.TI);
-      const int co = (int)(r / d.TI);
-      if (cp < d.Cin && tjp < d.TJ)
-        val = src[((int64_t)(ti * d.TJ + tjp) * d.Cin + cp) * d.Cout + co];
-    } else {
-      // dst[ci][ti][tj][cop]
-      int64_t r = i;
-      const int cop = (int)(r % d.CoutPad); r /= d.CoutPad;
-      const int tj = (int)(r % d.TJ); r /= d.TJ;
-      const int ti = (int)(r % d.TI);
-      const int ci = (int)(r / d.TI);
-      if (cop < d.Cout)
-        val = src[((int64_t)(ti * d.TJ + tj) * d.Cin + ci) * d.Cout + cop];
-    }
+    if (cop < d.Cout) val = src[((int64_t)(ti * d.TJ + tj) * d.Cin + ci) * d.Cout + cop];
     dst[i] = f2bf(val);
   }
 }

@@ -18,7 +18,7 @@ except ImportError as e:                      # pragma: no cover - exercised onl
   _import_error = e
 
 __all__ = ["available", "ext", "run_op", "Plan", "stream_handle", "sgd_momentum_l2",
-           "pack_desc_bytes", "PACK_PER_BLOCK"]
+           "pack_desc_bytes", "pack_blocks", "PACK_PER_BLOCK"]
 
 PACK_PER_BLOCK = 256 * 8
 
@@ -59,6 +59,15 @@ def sgd_momentum_l2(params: torch.Tensor, grads: torch.Tensor, velocity: torch.T
   run_op("sgd", dict(p=params.data_ptr(), g=grads.data_ptr(), v=velocity.data_ptr(),
                      l2x2=l2x2.data_ptr(), n=n, lr=float(lr), momentum=float(momentum),
                      grad_scale=float(grad_scale)))
+
+
+def pack_blocks(d: Dict) -> int:
+  """Thread blocks the weight-pack kernel spends on descriptor `d`: tiles of 32 input channels
+  x 64 output channels per tap for the forward layout (mode 0, a transpose), 2048 elements
+  per block for the data-gradient layout (mode 1, a strided copy)."""
+  if d["mode"] == 0:
+    return d["TI"] * d["TJpad"] * (-(-d["Cpad"] // 32)) * (-(-d["Cout"] // 64))
+  return -(-d["count"] // PACK_PER_BLOCK)
 
 
 def pack_desc_bytes(descs: Sequence[Dict]) -> bytes:

@@ -30,7 +30,7 @@ def _pack(native, g, w_hwio, which):
   desc = torch.frombuffer(bytearray(native.pack_desc_bytes([d])), dtype=torch.uint8).to(dev)
   native.run_op("pack_weights", dict(params=w_hwio.contiguous().data_ptr(), packed=out.data_ptr(),
                                      descs=desc.data_ptr(), ndesc=1,
-                                     nblocks=-(-d["count"] // native.PACK_PER_BLOCK)))
+                                     nblocks=native.pack_blocks(d)))
   torch.cuda.synchronize()
   return out
 
