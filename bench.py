@@ -51,6 +51,9 @@ def main() -> int:
   ap.add_argument("--no_graph", action="store_true")
   ap.add_argument("--executor", default="hip", choices=["hip", "torch"])
   a = ap.parse_args()
+  if os.environ.get("DTF_DEBUG_HANG"):      # dump every thread's stack if still running after N s
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ["DTF_DEBUG_HANG"]), exit=False)
 
   from distributed_tensorflow_amd import models
   from distributed_tensorflow_amd.data.synthetic import SyntheticDataset

@@ -13,7 +13,24 @@ from typing import Optional
 
 import torch
 
-__all__ = ["SyntheticDataset", "get_synth_input_fn"]
+__all__ = ["SyntheticDataset", "get_synth_input_fn", "set_up_synthetic_data",
+           "undo_set_up_synthetic_data"]
+
+# `set_up_synthetic_data()` (reference call site `resnet_imagenet_main.py:131`) patches the
+# strategy's iterator so that one batch stays on the device.  Here that is the default; after
+# `undo_set_up_synthetic_data()` the dataset keeps its batch in host memory and every step pays
+# the host->device copy, which is what the reference measures without the patch.
+_DEVICE_RESIDENT = True
+
+
+def set_up_synthetic_data():
+  global _DEVICE_RESIDENT
+  _DEVICE_RESIDENT = True
+
+
+def undo_set_up_synthetic_data():
+  global _DEVICE_RESIDENT
+  _DEVICE_RESIDENT = False
 
 
 class SyntheticDataset:
@@ -38,13 +55,23 @@ class SyntheticDataset:
       images = img.unsqueeze(0).expand(batch_size, -1, -1, -1).contiguous()
       labels = lab.to(torch.float32).unsqueeze(0).expand(batch_size, 1).contiguous()
     device = torch.device(device) if device is not None else torch.device("cpu")
-    self.images = images.to(device=device, dtype=dtype)
-    self.labels = labels.to(device)
+    self.device = device
+    self.resident = _DEVICE_RESIDENT or device.type == "cpu"
+    if self.resident:
+      self.images = images.to(device=device, dtype=dtype)
+      self.labels = labels.to(device)
+    else:
+      self.images = images.to(dtype).pin_memory()
+      self.labels = labels.pin_memory()
     self.batch_size = batch_size
 
   def __iter__(self):
     while True:
-      yield self.images, self.labels
+      if self.resident:
+        yield self.images, self.labels
+      else:
+        yield (self.images.to(self.device, non_blocking=True),
+               self.labels.to(self.device, non_blocking=True))
 
 
 def get_synth_input_fn(height, width, num_channels, num_classes, dtype=torch.float32,

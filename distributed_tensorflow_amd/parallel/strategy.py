@@ -30,7 +30,8 @@ from .allreduce import GradientReducer
 from .cluster import TaskInfo, resolve_task
 from .comm import Communicator, get_communicator
 
-__all__ = ["Strategy", "OneDeviceStrategy", "MirroredStrategy",
+__all__ = ["set_up_synthetic_data", "undo_set_up_synthetic_data",
+           "Strategy", "OneDeviceStrategy", "MirroredStrategy",
            "MultiWorkerMirroredStrategy", "get_distribution_strategy",
            "get_strategy_scope", "strategy_needs_launch"]
 
@@ -218,6 +219,17 @@ def get_distribution_strategy(distribution_strategy="default", num_gpus=0, num_w
     return ParameterServerStrategy(task, use_gpu)
 
   raise ValueError("Unrecognized Distribution Strategy: %r" % distribution_strategy)
+
+
+def set_up_synthetic_data():
+  """`distribution_utils.set_up_synthetic_data`: keep the synthetic batch on the device."""
+  from ..data import synthetic  # pylint: disable=import-outside-toplevel
+  synthetic.set_up_synthetic_data()
+
+
+def undo_set_up_synthetic_data():
+  from ..data import synthetic  # pylint: disable=import-outside-toplevel
+  synthetic.undo_set_up_synthetic_data()
 
 
 def get_strategy_scope(strategy):

@@ -159,12 +159,14 @@ def run_classifier(flags_obj, cfg: DatasetConfig, use_horovod: bool = False):
     num_shards = 1          # the Horovod drivers do not shard the input (reference parity)
 
   if flags_obj.use_synthetic_data:
+    strategy_lib.set_up_synthetic_data()
     input_fn = common.get_synth_input_fn(
         height=cfg.height, width=cfg.width, num_channels=cfg.channels,
         num_classes=cfg.num_classes, dtype=torch.float32, drop_remainder=True, device=device)
   else:
     if cfg.real_input_fn is None:
       raise ValueError("no on-disk input pipeline for %s" % cfg.name)
+    strategy_lib.undo_set_up_synthetic_data()
     input_fn = cfg.real_input_fn
 
   drop_remainder = flags_obj.enable_xla or not flags_obj.enable_get_next_as_optional
