@@ -15,3 +15,14 @@ Python package layout:
 * `hvd`         Horovod-style facade;  `launch`  one-process-per-GPU launcher
 """
 __version__ = "0.1.0"
+
+
+# HIP maps every stream of a process onto GPU_MAX_HW_QUEUES hardware queues (4 by default).
+# A training rank uses a compute stream, the collective library's streams, a hipGraph capture
+# stream and the prefetcher's copy stream; when they share a queue, a wait packet of one
+# stream holds back kernels of another (observed as a stalled step with gloo's host-staging
+# streams).  Eight queues keep them apart.  Only effective when set before the HIP runtime
+# initialises, which importing this package precedes.
+import os as _os
+
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

@@ -65,6 +65,13 @@ class GradientReducer:
     g = self._slice(b)
     c = self.comm
     self.bytes_reduced += g.numel() * 4
+    if g.is_cuda and c.backend != "nccl":
+      # gloo stages device tensors through the host on pool streams of its own.  With the
+      # default of four hardware queues per process those streams share a queue with the
+      # compute stream, and a step was seen to stall with kernels queued behind gloo's copies
+      # (it completes with GPU_MAX_HW_QUEUES=16).  gloo on GPU tensors is a test / rehearsal
+      # configuration, so the overlap is given up there: drain the compute stream first.
+      torch.cuda.current_stream(g.device).synchronize()
     if self.alg == "ring" and c.supports_reduce_scatter() and g.numel() % self.n == 0:
       shard = g.numel() // self.n
       r = c.rank if self.group is None else torch.distributed.get_rank(self.group)
