@@ -82,7 +82,7 @@ def _wgrad_candidates(desc: Dict) -> List[Tuple[int, int]]:
   elif cout <= 64:
     cfgs = [1, 3]
   else:
-    cfgs = [0, 2, 1]
+    cfgs = [0, 2, 1] + ([8] if ktotal >= 256 else [])
   if ktotal <= 64:
     cfgs = [c for c in cfgs if conv_plan.WGRAD_CFGS[c][0] <= 64] or cfgs
   out = []
@@ -98,10 +98,10 @@ def _wgrad_candidates(desc: Dict) -> List[Tuple[int, int]]:
       seen.add(s)
       out.append((c, s))
       # 2 / 4 wave groups per block share one atomic epilogue: same resident waves with
-      # half / a quarter of the blocks (cfg + 8 * log2(groups))
+      # half / a quarter of the blocks (cfg + 16 * log2(groups)); the 8-wave tile allows 2
       for lg, g in ((1, 2), (2, 4)):
-        if s >= g and (c + 8 * lg, -(-s // g)) not in out:
-          out.append((c + 8 * lg, -(-s // g)))
+        if s >= g and not (c == 8 and g == 4) and (c + 16 * lg, -(-s // g)) not in out:
+          out.append((c + 16 * lg, -(-s // g)))
   return out
 
 

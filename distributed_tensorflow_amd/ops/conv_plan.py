@@ -27,9 +27,9 @@ __all__ = ["ConvGeom", "round_up", "pick_fwd_cfg", "pick_wgrad_cfg"]
 # tile configurations compiled into the extension: cfg id -> (BM pixels, BN channels)
 FWD_CFGS = {0: (128, 128), 1: (256, 64), 2: (256, 32), 3: (256, 16), 4: (64, 128), 5: (128, 64),
             6: (256, 128)}
-# cfg id % 8 -> (BKK rows of dW, BCO output channels); cfg id // 8 = log2(wave groups per block)
+# cfg id % 16 -> (BKK rows of dW, BCO output channels); cfg id // 16 = log2(wave groups per block)
 WGRAD_CFGS = {0: (128, 128), 1: (128, 64), 2: (64, 128), 3: (64, 64), 4: (128, 32),
-              5: (128, 16), 6: (32, 32), 7: (64, 16)}
+              5: (128, 16), 6: (32, 32), 7: (64, 16), 8: (256, 128)}
 
 
 def round_up(x: int, m: int) -> int:

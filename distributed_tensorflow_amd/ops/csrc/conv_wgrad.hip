@@ -40,9 +40,11 @@ typedef __attribute__((address_space(3))) short4v lds_short4;
 // Byte offset of 16-byte chunk `ch` of pixel row `row` inside a [32][WIDTH] bf16 tile.
 template <int WIDTH>
 __device__ __forceinline__ int tile_off(int row, int ch) {
-  if constexpr (WIDTH == 128) {
+  if constexpr (WIDTH == 128 || WIDTH == 256) {
+    // rows are a whole number of 256-byte bank rows: XOR the low three bits of the 32-byte
+    // chunk index with a function that differs for the 8 rows one half-wave touches
     const int f = (row & 3) | (((row >> 3) & 1) << 2);
-    return row * 256 + ((((ch >> 1) ^ f) << 5) | ((ch & 1) << 4));
+    return row * (WIDTH * 2) + ((((ch >> 1) ^ f) << 5) | ((ch & 1) << 4));
   } else if constexpr (WIDTH == 64) {
     const int f = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
     return row * 128 + ((((ch >> 1) ^ f) << 5) | ((ch & 1) << 4));
@@ -68,23 +70,28 @@ __device__ __forceinline__ bf16x8 read_tr_frag(const uint8_t* tile, int c0, int 
 }
 
 template <int BKK, int BCO, int WAVES_K, int WAVES_C, int G, bool POINTWISE>
-__global__ __launch_bounds__(256 * G, 4) void conv_wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(64 * WAVES_K * WAVES_C * G, 4)
+void conv_wgrad_kernel(const WgradParams p) {
+  constexpr int GT = 64 * WAVES_K * WAVES_C;                    // threads per wave group
   constexpr int WKK = BKK / WAVES_K, WCO = BCO / WAVES_C;
   constexpr int KR = WKK / 16, CR = WCO / 16;
   constexpr int XCPR = BKK / 8, YCPR = BCO / 8;                 // 16-byte chunks per tile row
-  constexpr int XRPP = 256 / XCPR, YRPP = 256 / YCPR;           // tile rows filled per pass
+  constexpr int XRPP = GT / XCPR, YRPP = GT / YCPR;             // tile rows filled per pass
   constexpr int XV = (BP + XRPP - 1) / XRPP, YV = (BP + YRPP - 1) / YRPP;
   constexpr int XBYTES = BP * BKK * 2, YBYTES = BP * BCO * 2;
-  static_assert(WAVES_K * WAVES_C == 4, "4 waves per block");
+  static_assert(GT == 256 || GT == 512, "4 or 8 waves per group");
+  static_assert(GT * G <= 1024, "block size");
   static_assert(WKK % 16 == 0 && WCO % 16 == 0, "tile shape");
 
   constexpr int GBYTES = 2 * (XBYTES + YBYTES);                 // LDS of one group
-  static_assert(G == 1 || BKK * BCO * 4 <= G * GBYTES, "accumulator exchange must fit in LDS");
+  // accumulator rows (index a) exchanged per round through the block's LDS
+  constexpr int ACH = (G * GBYTES) / (CR * 16 * GT) < KR ? (G * GBYTES) / (CR * 16 * GT) : KR;
+  static_assert(G == 1 || ACH >= 1, "accumulator exchange must fit in LDS");
 
   __shared__ __attribute__((aligned(16))) uint8_t smem_all[G * GBYTES];
 
-  const int grp = threadIdx.x >> 8;                 // group of four waves
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;   // group-local ids
+  const int grp = threadIdx.x / GT;                 // wave group
+  const int tid = threadIdx.x % GT, lane = tid & 63, wave = tid >> 6;    // group-local ids
   const int wk = wave / WAVES_C, wc = wave % WAVES_C;
   uint8_t* smem = smem_all + grp * GBYTES;
 
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(256 * G, 4) void conv_wgrad_kernel(const WgradParam
   // ---- X (input) gather geometry: this thread always loads the same 8 k-columns ----------
   const int xrow = tid / XCPR, yrow = tid / YCPR;
   auto unswizzle = [](int width, int row, int slot) {
-    if (width == 128) return ((((slot >> 1) ^ ((row & 3) | (((row >> 3) & 1) << 2))) << 1) | (slot & 1));
+    if (width == 128 || width == 256) return ((((slot >> 1) ^ ((row & 3) | (((row >> 3) & 1) << 2))) << 1) | (slot & 1));
     if (width == 64) return ((((slot >> 1) ^ (((row >> 1) & 1) | (((row >> 3) & 1) << 1))) << 1) | (slot & 1));
     return slot;
   };
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(256 * G, 4) void conv_wgrad_kernel(const WgradParam
           ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
           if (ok) src = gx + ((size_t)(((int)n * p.H + hi) * p.W + wi) * p.Cpix + kc);
         }
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + r * 4096 + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + r * (GT * 16) + wave * 1024), 16, 0, 0);
       }
     }
 #pragma unroll
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256 * G, 4) void conv_wgrad_kernel(const WgradParam
         const int pp = pstep + row;
         const bool ok = yc_ok && pp < pend;
         const bf16_t* src = ok ? gy + ((size_t)pp * p.ldy + ycol) : zero_page;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ys + r * 4096 + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ys + r * (GT * 16) + wave * 1024), 16, 0, 0);
       }
     }
   };
@@ -198,24 +205,29 @@ __global__ __launch_bounds__(256 * G, 4) void conv_wgrad_kernel(const WgradParam
   if constexpr (G > 1) {
     float* red = reinterpret_cast<float*>(smem_all);
     for (int r = 1; r < G; ++r) {
-      if (grp == r) {
 #pragma unroll
-        for (int a = 0; a < KR; ++a)
+      for (int a0 = 0; a0 < KR; a0 += ACH) {
+        if (grp == r) {
 #pragma unroll
-          for (int b = 0; b < CR; ++b)
+          for (int a = a0; a < a0 + ACH && a < KR; ++a)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) red[((a * CR + b) * 4 + e) * 256 + tid] = acc[a][b][e];
+            for (int b = 0; b < CR; ++b)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                red[(((a - a0) * CR + b) * 4 + e) * GT + tid] = acc[a][b][e];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+          for (int a = a0; a < a0 + ACH && a < KR; ++a)
+#pragma unroll
+            for (int b = 0; b < CR; ++b)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                acc[a][b][e] += red[(((a - a0) * CR + b) * 4 + e) * GT + tid];
+        }
+        __syncthreads();
       }
-      __syncthreads();
-      if (grp == 0) {
-#pragma unroll
-        for (int a = 0; a < KR; ++a)
-#pragma unroll
-          for (int b = 0; b < CR; ++b)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[a][b][e] += red[((a * CR + b) * 4 + e) * 256 + tid];
-      }
-      __syncthreads();
     }
     if (grp != 0) return;
   }
@@ -256,10 +268,10 @@ void launch_grp(const WgradParams& p, hipStream_t stream) {
   dim3 grid(tilesK * tilesC, p.splits);
   if (pointwise)
     hipLaunchKernelGGL((conv_wgrad_kernel<BKK, BCO, WAVES_K, WAVES_C, G, true>), grid,
-                       dim3(256 * G), 0, stream, p);
+                       dim3(64 * WAVES_K * WAVES_C * G), 0, stream, p);
   else
     hipLaunchKernelGGL((conv_wgrad_kernel<BKK, BCO, WAVES_K, WAVES_C, G, false>), grid,
-                       dim3(256 * G), 0, stream, p);
+                       dim3(64 * WAVES_K * WAVES_C * G), 0, stream, p);
 }
 
 template <int BKK, int BCO, int WAVES_K, int WAVES_C>
@@ -267,8 +279,13 @@ void launch_cfg(const WgradParams& p, int groups, hipStream_t stream) {
   switch (groups) {
     case 1: launch_grp<BKK, BCO, WAVES_K, WAVES_C, 1>(p, stream); break;
     case 2: launch_grp<BKK, BCO, WAVES_K, WAVES_C, 2>(p, stream); break;
-    case 4: launch_grp<BKK, BCO, WAVES_K, WAVES_C, 4>(p, stream); break;
-    default: throw std::invalid_argument("conv_wgrad: groups must be 1, 2 or 4");
+    case 4:
+      if constexpr (WAVES_K * WAVES_C == 4) {
+        launch_grp<BKK, BCO, WAVES_K, WAVES_C, 4>(p, stream);
+        break;
+      }
+      [[fallthrough]];
+    default: throw std::invalid_argument("conv_wgrad: unsupported number of wave groups");
   }
 }
 
@@ -297,13 +314,13 @@ void validate_wgrad_params(const WgradParams& p) {
   }
 }
 
-// cfg = tile id (0..7) + 8 * log2(groups): 0..7 one group of four waves per block, 8..15 two
-// groups, 16..23 four groups.
+// cfg = tile id (0..15) + 16 * log2(groups): 1, 2 or 4 wave groups per block (tile 8, whose
+// groups have eight waves, allows 1 or 2).
 void launch_conv_wgrad(const WgradParams& p, int cfg, hipStream_t stream) {
   validate_wgrad_params(p);
-  if (cfg < 0 || cfg >= 24) throw std::invalid_argument("conv_wgrad: unknown tile config");
-  const int g = 1 << (cfg / 8);
-  switch (cfg % 8) {
+  if (cfg < 0 || cfg >= 48) throw std::invalid_argument("conv_wgrad: unknown tile config");
+  const int g = 1 << (cfg / 16);
+  switch (cfg % 16) {
     case 0: launch_cfg<128, 128, 2, 2>(p, g, stream); break;
     case 1: launch_cfg<128, 64, 2, 2>(p, g, stream); break;
     case 2: launch_cfg<64, 128, 2, 2>(p, g, stream); break;
@@ -312,5 +329,7 @@ void launch_conv_wgrad(const WgradParams& p, int cfg, hipStream_t stream) {
     case 5: launch_cfg<128, 16, 4, 1>(p, g, stream); break;
     case 6: launch_cfg<32, 32, 2, 2>(p, g, stream); break;
     case 7: launch_cfg<64, 16, 4, 1>(p, g, stream); break;
+    case 8: launch_cfg<256, 128, 4, 2>(p, g, stream); break;   // 8 waves: 96 FLOP per L2 byte
+    default: throw std::invalid_argument("conv_wgrad: unknown tile config");
   }
 }

@@ -179,11 +179,11 @@ def test_conv_every_tile_config(cfg, shape):
   assert (dx.float() - xr.grad).abs().max().item() <= 0.02 * xr.grad.abs().max().item() + 1e-2
 
 
-@pytest.mark.parametrize("cfg,splits", [(0, 5), (8, 3), (16, 2), (10, 4), (19, 1), (9, 7), (20, 2),
-                                        (14, 3), (23, 2)])
+@pytest.mark.parametrize("cfg,splits", [(0, 5), (16, 3), (32, 2), (18, 4), (35, 1), (17, 7), (36, 2),
+                                        (22, 3), (39, 2), (8, 2), (24, 3)])
 @pytest.mark.parametrize("shape", [(3, 19, 19, 64, 3, 136, 2), (2, 15, 15, 96, 1, 72, 1)])
 def test_wgrad_every_tile_config_and_group_count(cfg, splits, shape):
-  """Weight gradient under every tile / wave-group combination (cfg = tile + 8*log2(groups))."""
+  """Weight gradient under every tile / wave-group combination (cfg = tile + 16*log2(groups))."""
   native = _native()
   N, H, W, Cin, K, Cout, stride = shape
   dev = torch.device("cuda")
