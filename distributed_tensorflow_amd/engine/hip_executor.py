@@ -74,15 +74,22 @@ class HipExecutor:
     self.N = int(batch_size)
     self.device = store.device
     self.buckets = buckets if buckets is not None else store.make_buckets(1)
-    if use_graph is None:
-      use_graph = os.environ.get("DTF_HIP_GRAPH", "1") != "0"
+    # True: replay the step as a hipGraph; False: enqueue the plan from C++ every step; None
+    # ("auto", or DTF_HIP_GRAPH unset): time a few steps each way and keep the faster - graph
+    # replay removes the launch overhead that dominates small models, eager launch lets the
+    # side lane really overlap the main lane, which wins on large ones
+    if use_graph is None and "DTF_HIP_GRAPH" in os.environ:
+      use_graph = os.environ["DTF_HIP_GRAPH"] != "0"
     self.use_graph = use_graph
+    self._calib: Dict[str, list] = {"eager": [], "graph": []}
+    self._calib_step = 0
     # BatchNorm statistics accumulated in the convolution epilogue with float atomics (one
     # sweep over the activations less, summation order not fixed) or by the separate
     # deterministic sweep
     if fused_bn_stats is None:
       fused_bn_stats = os.environ.get("DTF_BN_FUSED_STATS", "1") != "0"
     self.fused_bn_stats = fused_bn_stats
+    self.overlap_wgrad = os.environ.get("DTF_WGRAD_STREAM", "1") != "0"
     self._keep: List[torch.Tensor] = []      # owns every planned buffer
     self._graph_stream: Optional[torch.cuda.Stream] = None
     self._train_graph = None
@@ -245,11 +252,21 @@ class HipExecutor:
     self._pack_args = dict(params=self.store.params.data_ptr(), packed=self.packed.data_ptr(),
                            descs=self.pack_descs.data_ptr(), ndesc=len(descs), nblocks=blk)
 
-  def _add(self, plan, kind: str, desc: Dict, name: str):
+  def _add(self, plan, kind: str, desc: Dict, name: str, lane: int = 0):
     """plan.add with the measured tile configuration of this shape, when one is known."""
     if kind in ("conv", "wgrad"):
       desc = autotune.apply(kind, desc)
-    plan.add(kind, desc, name)
+    plan.add(kind, desc, name, lane)
+
+  def _add_wgrad(self, plan, desc: Dict, name: str):
+    """Weight gradients run on the plan's side lane: they depend only on tensors that are
+    complete at this point and nothing but the bucket's all-reduce / the optimizer consumes
+    them, so they overlap the BatchNorm / data-gradient chain."""
+    if self.overlap_wgrad:
+      plan.add("fork", {}, name + "/fork")
+      self._add(plan, "wgrad", desc, name, lane=1)
+    else:
+      self._add(plan, "wgrad", desc, name)
 
   def _wf_ptr(self, name):
     return self.packed.data_ptr() + 2 * self._wf[name]
@@ -360,6 +377,8 @@ class HipExecutor:
         if remaining[bi] == 0:
           ready.append(by_index[bi])
       if ready:
+        if self.overlap_wgrad:
+          plan.add("join", {}, "join")        # the bucket's gradients are complete past here
         self._segments.append((seg_begin, plan.size(), ready))
         seg_begin = plan.size()
 
@@ -378,8 +397,9 @@ class HipExecutor:
         g = self.geoms[op.name]
         plan.add("colsum", dict(x=dout.data_ptr(), out=self._var_ptr(op.name + "/bias", "grad"),
                                 N=N, C=g.Cout, ld=g.ldc), op.name + "/dbias")
-        self._add(plan, "wgrad", g.wgrad(acts[xname].data_ptr(), dout.data_ptr(),
-                                  self._var_ptr(op.name + "/kernel", "grad")), op.name + "/wgrad")
+        self._add_wgrad(plan, g.wgrad(acts[xname].data_ptr(), dout.data_ptr(),
+                                      self._var_ptr(op.name + "/kernel", "grad")),
+                        op.name + "/wgrad")
         dx = grad_buf(xname)
         for d in g.dgrad(dout.data_ptr(), self._wd_ptr(op.name), dx.data_ptr(),
                          accumulate=xname in written):
@@ -436,8 +456,9 @@ class HipExecutor:
         done([op.name + "/gamma", op.name + "/beta"])
       elif op.kind == "conv":
         g = self.geoms[op.name]
-        self._add(plan, "wgrad", g.wgrad(acts[xname].data_ptr(), dout.data_ptr(),
-                                  self._var_ptr(op.name + "/kernel", "grad")), op.name + "/wgrad")
+        self._add_wgrad(plan, g.wgrad(acts[xname].data_ptr(), dout.data_ptr(),
+                                      self._var_ptr(op.name + "/kernel", "grad")),
+                        op.name + "/wgrad")
         if op is not first_conv:
           dx = grad_buf(xname)
           add, add_mask = None, None
@@ -452,6 +473,8 @@ class HipExecutor:
           written.add(xname)
         done([op.name + "/kernel"])
     if seg_begin < plan.size() or not self._segments:
+      if self.overlap_wgrad:
+        plan.add("join", {}, "join")
       self._segments.append((seg_begin, plan.size(), []))
     left = [i for i, r in remaining.items() if r]
     if left:
@@ -516,7 +539,9 @@ class HipExecutor:
       self._ensure_packed()
       self._stage(images, labels)
       self._set_loss_scale(loss_scale)
-      if on_bucket_ready is None and self.use_graph:
+      if on_bucket_ready is None and self.use_graph is None:
+        self._calibrate_step()
+      elif on_bucket_ready is None and self.use_graph:
         self._run_train_graph()
       else:
         s = native.stream_handle(self.device)
@@ -528,6 +553,37 @@ class HipExecutor:
               on_bucket_ready(b)
       out = self.accum.clone()
     return out[0] / self.N, out[1]
+
+  def _run_eager(self):
+    s = native.stream_handle(self.device)
+    self.fwd_plan.run(0, self.fwd_plan.size(), s)
+    self.bwd_plan.run(0, self.bwd_plan.size(), s)
+
+  def _calibrate_step(self):
+    """Auto mode: steps 0-3 eager (2-3 timed), step 4 captures, steps 5-7 replay (6-7 timed)."""
+    i = self._calib_step
+    self._calib_step += 1
+    mode = "eager" if i < 4 else "graph"
+    timed = i in (2, 3, 6, 7)
+    if timed:
+      t0 = torch.cuda.Event(enable_timing=True)
+      t1 = torch.cuda.Event(enable_timing=True)
+      t0.record()
+    if mode == "eager":
+      self._run_eager()
+    else:
+      self._run_train_graph()
+    if timed:
+      t1.record()
+      self._calib[mode].append((t0, t1))
+    if i == 7:
+      torch.cuda.synchronize(self.device)
+      ms = {m: min(a.elapsed_time(b) for a, b in ev) for m, ev in self._calib.items()}
+      self.use_graph = ms["graph"] <= ms["eager"]
+      logging.info("HipExecutor %s: eager %.3f ms, hipGraph replay %.3f ms per step -> %s",
+                   self.spec.name, ms["eager"], ms["graph"],
+                   "graph" if self.use_graph else "eager")
+      self._calib = {}
 
   def _run_train_graph(self):
     """Forward + backward as one hipGraph (captured at first use on a side stream)."""

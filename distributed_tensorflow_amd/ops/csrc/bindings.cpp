@@ -255,6 +255,12 @@ void check_launch() {
   if (e != hipSuccess) throw std::runtime_error(std::string("kernel launch failed: ") + hipGetErrorString(e));
 }
 
+// A plan has two lanes.  Lane 0 is the caller's stream; lane 1 is a side stream owned by the
+// plan, used for work that is independent of the main dependency chain (weight gradients next to
+// the BatchNorm / data-gradient chain of the backward pass: atomics- and MFMA-bound kernels
+// next to bandwidth-bound ones).  "fork" makes the side lane wait for everything enqueued on
+// the main lane so far, "join" makes the main lane wait for the side lane.  Under stream capture
+// the same event calls become graph edges, so a replayed hipGraph has the two branches too.
 class Plan {
  public:
   ~Plan() {
@@ -262,28 +268,43 @@ class Plan {
       if (g.exec) (void)hipGraphExecDestroy(g.exec);
       if (g.graph) (void)hipGraphDestroy(g.graph);
     }
+    for (auto e : events_) (void)hipEventDestroy(e);
+    if (side_) (void)hipStreamDestroy(side_);
   }
-  int add(const std::string& kind, const py::dict& args, const std::string& name) {
-    ops_.push_back(make_op(kind, args));
+  int add(const std::string& kind, const py::dict& args, const std::string& name, int lane) {
+    if (lane != 0 && lane != 1) throw std::invalid_argument("Plan.add: lane must be 0 or 1");
+    Entry e;
+    e.lane = lane;
+    if (kind == "fork") e.type = FORK;
+    else if (kind == "join") e.type = JOIN;
+    else e.launch = make_op(kind, args);
+    if (e.type != OP) {
+      hipEvent_t ev;
+      HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      events_.push_back(ev);
+      e.event = ev;
+    }
+    ops_.push_back(std::move(e));
     names_.push_back(name.empty() ? kind : name);
     return (int)ops_.size() - 1;
   }
   int size() const { return (int)ops_.size(); }
   std::string name(int i) const { return names_.at(i); }
+  int lane(int i) const { return ops_.at(i).lane; }
   void run(int begin, int end, uintptr_t stream) {
     if (begin < 0 || end > (int)ops_.size() || begin > end) throw std::out_of_range("Plan.run range");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    for (int i = begin; i < end; ++i) ops_[i](s);
+    enqueue(begin, end, reinterpret_cast<hipStream_t>(stream));
     check_launch();
   }
   // Captures ops [begin, end) on `stream` into a hipGraph; returns a handle for replay().
+  // The range must end with the side lane joined (the capture cannot end otherwise).
   int capture(int begin, int end, uintptr_t stream) {
     if (begin < 0 || end > (int)ops_.size() || begin > end) throw std::out_of_range("Plan.capture range");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     Graph g;
     HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     try {
-      for (int i = begin; i < end; ++i) ops_[i](s);
+      enqueue(begin, end, s);
     } catch (...) {
       hipGraph_t tmp = nullptr;
       (void)hipStreamEndCapture(s, &tmp);
@@ -300,10 +321,47 @@ class Plan {
   }
 
  private:
+  enum Type { OP, FORK, JOIN };
+  struct Entry {
+    Type type = OP;
+    int lane = 0;
+    Launch launch;
+    hipEvent_t event = nullptr;
+  };
   struct Graph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
-  std::vector<Launch> ops_;
+
+  hipStream_t side() {
+    if (!side_) HIP_CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+    return side_;
+  }
+  void enqueue(int begin, int end, hipStream_t main) {
+    bool side_busy = false;          // side lane holds work the main lane has not waited for
+    for (int i = begin; i < end; ++i) {
+      Entry& e = ops_[i];
+      if (e.type == FORK) {
+        HIP_CHECK(hipEventRecord(e.event, main));
+        HIP_CHECK(hipStreamWaitEvent(side(), e.event, 0));
+      } else if (e.type == JOIN) {
+        if (side_busy) {
+          HIP_CHECK(hipEventRecord(e.event, side()));
+          HIP_CHECK(hipStreamWaitEvent(main, e.event, 0));
+          side_busy = false;
+        }
+      } else if (e.lane == 1) {
+        e.launch(side());
+        side_busy = true;
+      } else {
+        e.launch(main);
+      }
+    }
+    if (side_busy) throw std::logic_error("Plan: range ends with unjoined side-lane work");
+  }
+
+  std::vector<Entry> ops_;
   std::vector<std::string> names_;
   std::vector<Graph> graphs_;
+  std::vector<hipEvent_t> events_;
+  hipStream_t side_ = nullptr;
 };
 
 }  // namespace
@@ -321,7 +379,9 @@ PYBIND11_MODULE(_dtf_native, m) {
   m.attr("arch") = "gfx950";
   py::class_<Plan>(m, "Plan")
       .def(py::init<>())
-      .def("add", &Plan::add, py::arg("kind"), py::arg("args"), py::arg("name") = "")
+      .def("add", &Plan::add, py::arg("kind"), py::arg("args"), py::arg("name") = "",
+           py::arg("lane") = 0)
+      .def("lane", &Plan::lane)
       .def("size", &Plan::size)
       .def("name", &Plan::name)
       .def("run", &Plan::run, py::arg("begin"), py::arg("end"), py::arg("stream") = 0)
