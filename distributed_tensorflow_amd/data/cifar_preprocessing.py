@@ -78,6 +78,11 @@ def parse_record(raw_record: bytes, is_training: bool, dtype="fp32", rng=None):
   return image, onehot
 
 
+def torch_device_type(device) -> str:
+  import torch  # pylint: disable=import-outside-toplevel
+  return torch.device(device).type
+
+
 def get_filenames(is_training: bool, data_dir: str):
   """Returns a list of filenames."""
   assert os.path.exists(data_dir), (
@@ -100,6 +105,20 @@ def input_fn(is_training, data_dir, batch_size, num_epochs=1, dtype="fp32",
   if num_shards > 1:
     logging.info("Sharding the dataset: input_pipeline_id=%d num_input_pipelines=%d",
                  shard_index, num_shards)
+  from . import native_loader  # pylint: disable=import-outside-toplevel
+  if (parse_record_fn is None or parse_record_fn is parse_record) and native_loader.available():
+    # C++ pipeline: same records, same augmentation, a thread pool instead of worker processes
+    on_gpu = device is not None and torch_device_type(device) == "cuda"
+    ds = native_loader.NativeCifarDataset(
+        filenames, is_training, batch_size, num_epochs=None if is_training else num_epochs,
+        shard_index=shard_index, num_shards=num_shards,
+        num_threads=datasets_num_private_threads, drop_remainder=drop_remainder,
+        pin_memory=on_gpu, ring=6 if tf_data_experimental_slack else 4)
+    delay = float(os.environ.get("DTF_DATA_PREFETCH_DELAY_MS", "0"))
+    pf = pipeline.DevicePrefetcher(ds, device if device is not None else "cpu",
+                                   depth=3 if tf_data_experimental_slack else 2, delay_ms=delay)
+    pf.batch_size = batch_size
+    return pf
   ds = pipeline.RecordDataset(
       filenames, read_fixed_length_records, parse_record_fn or parse_record, is_training,
       shuffle_buffer=NUM_IMAGES["train"], num_epochs=None if is_training else num_epochs,

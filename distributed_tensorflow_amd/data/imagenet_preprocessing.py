@@ -62,6 +62,12 @@ def get_filenames(is_training: bool, data_dir: str):
 
 
 def read_tfrecords(path: str) -> Iterator[bytes]:
+  """Record payloads of one shard; framing and CRC-32C checks run in the C++ module when it
+  is built (a shard is ~140 MB: the pure-Python checksum would dominate the input pipeline)."""
+  from . import native_loader  # pylint: disable=import-outside-toplevel
+  if native_loader.available():
+    yield from native_loader.read_tfrecords(path, verify=True)
+    return
   with open(path, "rb") as f:
     yield from tfrecord.read_records(f)
 

@@ -53,8 +53,30 @@ def _compile(src, force):
   return obj, True
 
 
+def data_so_path() -> str:
+  return os.path.join(HERE, "_dtf_data" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_data(force: bool = False, verbose: bool = True) -> str:
+  """Host-only module `_dtf_data` (input pipeline): plain g++, no GPU code."""
+  src = os.path.join(CSRC, "data_loader.cpp")
+  target = data_so_path()
+  if force or _stale(target, [src]):
+    cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-fvisibility=hidden",
+           src, "-o", target] + _includes()
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+      raise RuntimeError("g++ failed for data_loader.cpp:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+      print("built", target)
+  elif verbose:
+    print("up to date:", target)
+  return target
+
+
 def build(force: bool = False, jobs: int = 4, verbose: bool = True) -> str:
   os.makedirs(OBJ, exist_ok=True)
+  build_data(force, verbose)
   with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
     results = list(ex.map(lambda s: _compile(s, force), SOURCES))
   objs = [o for o, _ in results]

@@ -158,3 +158,74 @@ def test_synthetic_input_matches_reference_contract():
   assert 0 <= x.min() and x.max() <= 255
   x2, _ = next(iter(ds))
   assert x2.data_ptr() == x.data_ptr()                           # same resident batch every step
+
+
+def test_native_cifar_loader_matches_python_pipeline(tmp_path):
+  """The C++ loader yields exactly the records / preprocessing of the Python map function."""
+  from distributed_tensorflow_amd.data import native_loader
+  if not native_loader.available():
+    pytest.skip("_dtf_data not built")
+  _write_cifar(str(tmp_path), per_file=20)
+  files = cifar.get_filenames(False, str(tmp_path))
+  ds = native_loader.NativeCifarDataset(files, False, batch_size=7, num_epochs=1)
+  got_x, got_y = [], []
+  for x, y in ds:
+    got_x.append(x.clone()); got_y.append(y.clone())
+  gx, gy = torch.cat(got_x), torch.cat(got_y)
+  ref = [cifar.parse_record(r, False) for r in cifar.read_fixed_length_records(files[0])]
+  rx = torch.from_numpy(np.stack([a for a, _ in ref]))
+  ry = torch.from_numpy(np.stack([b for _, b in ref]))
+  assert gx.shape == rx.shape and torch.allclose(gx, rx, atol=1e-4)
+  assert torch.equal(gy, ry)
+  # a second pass starts from the first record again
+  assert torch.allclose(next(iter(ds))[0], rx[:7], atol=1e-4)
+  # training: every record once per epoch, standardised crops, batches span epochs
+  tr = native_loader.NativeCifarDataset(cifar.get_filenames(True, str(tmp_path)), True, 16,
+                                        num_epochs=None, seed=3, num_threads=3)
+  assert tr.num_records == 100
+  it = iter(tr)
+  labels = []
+  for _ in range(25):                                     # 400 samples = 4 epochs
+    x, y = next(it)
+    assert x.shape == (16, 32, 32, 3)
+    assert torch.allclose(x.mean(dim=(1, 2, 3)), torch.zeros(16), atol=1e-4)
+    assert torch.allclose(x.std(dim=(1, 2, 3), unbiased=False), torch.ones(16), atol=1e-3)
+    labels.append(y.argmax(1))
+  labels = torch.cat(labels)
+  all_ref = torch.cat([torch.tensor([cifar.parse_record(r, False)[1].argmax()
+                                     for r in cifar.read_fixed_length_records(f)])
+                       for f in cifar.get_filenames(True, str(tmp_path))])
+  for e in range(4):                                      # same label histogram each epoch
+    assert torch.equal(torch.bincount(labels[100 * e:100 * (e + 1)], minlength=10),
+                       torch.bincount(all_ref, minlength=10))
+  assert not torch.equal(labels[:100], labels[100:200])   # reshuffled between epochs
+  # shards are disjoint and cover the file
+  n = [native_loader.NativeCifarDataset(files, False, 4, num_epochs=1, shard_index=s,
+                                        num_shards=3).num_records for s in range(3)]
+  assert sum(n) == 20 and max(n) - min(n) <= 1
+
+
+def test_native_crc_and_tfrecord_reader(tmp_path):
+  from distributed_tensorflow_amd.data import native_loader
+  from distributed_tensorflow_amd.utils import tfrecord
+  if not native_loader.available():
+    pytest.skip("_dtf_data not built")
+  ext = native_loader.ext()
+  rng = np.random.default_rng(0)
+  for n in (0, 1, 7, 8, 9, 63, 1000):
+    data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    assert ext.crc32c(data) == tfrecord.crc32c(data)
+    assert ext.masked_crc32c(data) == tfrecord.masked_crc32c(data)
+  assert ext.crc32c(b"123456789") == 0xE3069283              # CRC-32C check value
+  path = str(tmp_path / "x.tfrecord")
+  payloads = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (5, 0, 300, 17)]
+  with open(path, "wb") as f:
+    for p in payloads:
+      tfrecord.write_record(f, p)
+  assert native_loader.read_tfrecords(path) == payloads
+  raw = bytearray(open(path, "rb").read())
+  raw[12 + 2] ^= 0x55                                          # flip a payload byte
+  open(path, "wb").write(bytes(raw))
+  with pytest.raises(RuntimeError, match="checksum"):
+    native_loader.read_tfrecords(path)
+  assert len(native_loader.read_tfrecords(path, verify=False)) == 4
