@@ -37,18 +37,21 @@ def round_up(x: int, m: int) -> int:
 
 
 def pick_fwd_cfg(M: int, cout: int) -> int:
-  """Tile choice for the forward / data-gradient GEMM (M pixels x cout channels)."""
+  """Tile choice for the forward / data-gradient GEMM (M pixels x cout channels) when the
+  shape has no measured entry; the rules summarise what the measurements of the ResNet
+  shapes prefer."""
   if cout <= 16:
     return 3
   if cout <= 32:
     return 2
   if cout <= 64:
-    # 256x64 when there is enough work to fill the chip, else 128x64
-    return 1 if -(-M // 256) >= 512 else 5
-  blocks = -(-M // 128) * -(-cout // 128)
-  if blocks < 600:
-    return 4          # 64x128: twice the blocks for the small late-stage layers
-  return 0
+    return 5          # 128x64 (beat 256x64 on every measured shape)
+  nt = -(-cout // 128)
+  if -(-M // 256) * nt >= 256:
+    return 6          # 8 waves, 256x128: most FLOP per L2 byte, if it still fills the chip
+  if -(-M // 128) * nt >= 256:
+    return 0
+  return 4            # 64x128: twice the blocks for the small late-stage layers
 
 
 def pick_wgrad_cfg(ktotal: int, cout: int, P: int, target_blocks: int = 0) -> Tuple[int, int]:
@@ -74,6 +77,10 @@ def pick_wgrad_cfg(ktotal: int, cout: int, P: int, target_blocks: int = 0) -> Tu
   bkk, bco = WGRAD_CFGS[cfg]
   tiles = -(-ktotal // bkk) * -(-cout // bco)
   splits = max(1, min(-(-target_blocks // tiles), max(P // 256, 1)))
+  if splits >= 4:
+    # two wave groups per block share one atomic epilogue (half the atomic traffic at the
+    # same number of resident waves): preferred by most measured shapes
+    return cfg + 16, -(-splits // 2)
   return cfg, splits
 
 

@@ -27,13 +27,13 @@ def test_signature_ignores_addresses_and_choices():
 def test_apply_uses_cache_and_falls_back(tmp_path, monkeypatch):
   g = _geom()
   d = g.wgrad(1, 2, 3)
-  cache = {autotune.signature("wgrad", d): {"cfg": 16, "splits": 5, "us": 1.0}}
+  cache = {autotune.signature("wgrad", d): {"cfg": 34, "splits": 5, "us": 1.0}}
   p = tmp_path / "tuned.json"
   p.write_text(json.dumps(cache))
   monkeypatch.setenv("DTF_AUTOTUNE_CACHE", str(p))
   monkeypatch.setattr(autotune, "_cache", None)
   out = autotune.apply("wgrad", d)
-  assert out["cfg"] == 16 and out["splits"] == 5 and d["cfg"] != 16      # input left untouched
+  assert out["cfg"] == 34 and out["splits"] == 5 and d["cfg"] != 34      # input left untouched
   other = ConvGeom(8, 7, 7, 64, 1, 1, 64).wgrad(1, 2, 3)
   assert autotune.apply("wgrad", other) == other                          # heuristic choice kept
   monkeypatch.setattr(autotune, "_cache", None)
