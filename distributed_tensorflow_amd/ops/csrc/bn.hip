@@ -45,7 +45,27 @@ __device__ __forceinline__ void block_reduce_to_partials(float (&part)[NV], int 
   __shared__ float red[TPB * NV];
   const int tid = threadIdx.x;
   const int rpb = TPB / tpr;
-  if (rpb > 1) {
+  if (tpr < 64) {
+    // several lanes of a wave own the same chunk (lane % tpr): butterfly over those first,
+    // then one LDS round over the four waves (a serial loop over the block's 32..256 rows made
+    // this epilogue longer than the sweep itself on small tensors)
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int off = tpr; off < 64; off <<= 1) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) part[i] += __shfl_xor(part[i], off);
+    }
+    if (lane < tpr) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) red[(i * 4 + wave) * 64 + lane] = part[i];
+    }
+    __syncthreads();
+    if (tid < tpr) {                       // rowid == 0 and chunk == tid
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        part[i] = (red[(i * 4 + 0) * 64 + tid] + red[(i * 4 + 1) * 64 + tid]) +
+                  (red[(i * 4 + 2) * 64 + tid] + red[(i * 4 + 3) * 64 + tid]);
+    }
+  } else if (rpb > 1) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) red[i * TPB + tid] = part[i];
     __syncthreads();
