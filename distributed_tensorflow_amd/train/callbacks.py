@@ -21,7 +21,7 @@ import numpy as np
 from ..utils import logging
 from ..utils import tfrecord
 
-__all__ = ["Callback", "CallbackList", "History", "BatchTimestamp", "TimeHistory",
+__all__ = ["StopAtThreshold", "Callback", "CallbackList", "History", "BatchTimestamp", "TimeHistory",
            "LearningRateBatchScheduler", "ProfilerCallback", "get_profiler_callback",
            "TensorBoard", "ModelCheckpoint"]
 
@@ -286,6 +286,22 @@ class TensorBoard(Callback):
     if self._f is not None:
       self._f.close()
       self._f = None
+
+
+class StopAtThreshold(Callback):
+  """`--stop_threshold`: ends training once the evaluation accuracy reaches the threshold
+  (`model_helpers.past_stop_threshold` applied to the validation metric of an epoch)."""
+
+  def __init__(self, threshold, metric: str):
+    super().__init__()
+    self.threshold = threshold
+    self.metric = metric
+
+  def on_epoch_end(self, epoch, logs=None):
+    from ..utils import model_helpers  # pylint: disable=import-outside-toplevel
+    val = (logs or {}).get("val_" + self.metric)
+    if val is not None and model_helpers.past_stop_threshold(self.threshold, val):
+      self.model.stop_training = True
 
 
 class ModelCheckpoint(Callback):

@@ -26,7 +26,7 @@ from ..parallel import strategy as strategy_lib
 from ..utils import flags as flags_core
 from ..utils import keras_utils
 from ..utils import logging
-from .callbacks import ModelCheckpoint
+from .callbacks import ModelCheckpoint, StopAtThreshold
 from .model import Model
 from .optimizers import LossScaleOptimizer
 from .schedules import PiecewiseConstantDecayWithWarmup
@@ -231,6 +231,9 @@ def run_classifier(flags_obj, cfg: DatasetConfig, use_horovod: bool = False):
 
   # ---- callbacks and step accounting ------------------------------------------------------
   callbacks = common.get_callbacks(cfg.learning_rate_schedule, cfg.num_images["train"])
+
+  if flags_obj.stop_threshold is not None and not flags_obj.skip_eval:
+    callbacks.append(StopAtThreshold(flags_obj.stop_threshold, cfg.accuracy_metric))
 
   train_steps = cfg.num_images["train"] // global_batch
   train_epochs = flags_obj.train_epochs

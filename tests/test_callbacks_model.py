@@ -113,3 +113,18 @@ def test_profiler_callback_writes_trace(tmp_path):
   p = cb.get_profiler_callback(str(tmp_path), "2,3")
   m.fit(ds, epochs=1, steps_per_epoch=4, callbacks=[p], verbose=0)
   assert os.path.exists(tmp_path / "profile_steps_2_3.trace.json")
+
+
+def test_stop_at_threshold_callback():
+  from distributed_tensorflow_amd.train.callbacks import StopAtThreshold
+
+  class _M:
+    stop_training = False
+  cb = StopAtThreshold(0.5, "categorical_accuracy")
+  cb.model = _M()
+  cb.on_epoch_end(0, {"val_categorical_accuracy": 0.4})
+  assert not cb.model.stop_training
+  cb.on_epoch_end(1, {"loss": 1.0})                       # no validation this epoch
+  assert not cb.model.stop_training
+  cb.on_epoch_end(2, {"val_categorical_accuracy": 0.6})
+  assert cb.model.stop_training
