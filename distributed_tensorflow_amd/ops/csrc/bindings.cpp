@@ -13,6 +13,7 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <cstdlib>
 #include <functional>
 #include <stdexcept>
 #include <string>
@@ -331,7 +332,16 @@ class Plan {
   struct Graph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
 
   hipStream_t side() {
-    if (!side_) HIP_CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+    if (!side_) {
+      // DTF_SIDE_PRIORITY: "low" / "high" place the side lane below / above the main lane
+      int lo = 0, hi = 0;
+      HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo: least urgent, hi: most
+      const char* e = std::getenv("DTF_SIDE_PRIORITY");
+      int prio = 0;
+      if (e && std::string(e) == "low") prio = lo;
+      if (e && std::string(e) == "high") prio = hi;
+      HIP_CHECK(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, prio));
+    }
     return side_;
   }
   void enqueue(int begin, int end, hipStream_t main) {

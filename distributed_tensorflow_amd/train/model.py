@@ -35,10 +35,17 @@ SUPPORTED_LOSSES = ("sparse_categorical_crossentropy", "categorical_crossentropy
 
 
 def _pick_executor_kind(requested: str, device: torch.device, dtype: str) -> str:
+  """auto: the native engine for 16-bit training on a GPU, PyTorch ops otherwise.
+
+  The native engine's 16-bit format is bfloat16 (fp32 accumulation, fp32 master weights).
+  `--dtype fp16`, the reference's mixed-precision switch (`resnet_imagenet_main.py:97-100`),
+  selects the same engine: activations are then bfloat16 rather than IEEE half, and the loss
+  scale the fp16 recipe asks for is still applied and removed (it is harmless with bfloat16's
+  fp32-sized exponent).  `--executor torch` runs true fp16 through PyTorch instead."""
   if requested != "auto":
     return requested
-  if device.type == "cuda" and dtype in ("bf16", "bfloat16"):
-    return "hip"
+  if device.type == "cuda" and dtype in ("bf16", "bfloat16", "fp16"):
+    return "hip"      # a missing extension is an error on a GPU machine, not a silent fallback
   return "torch"
 
 
@@ -118,7 +125,9 @@ class Model:
     if ex is None:
       if self.executor_kind == "hip":
         from ..engine.hip_executor import HipExecutor  # pylint: disable=import-outside-toplevel
-        ex = HipExecutor(self.spec, self.store, batch, self.dtype, self._bucket_list(),
+        if self.dtype == "fp16":
+          logging.warning("--dtype fp16: the native engine computes in bfloat16")
+        ex = HipExecutor(self.spec, self.store, batch, "bf16", self._bucket_list(),
                          use_graph=self.use_hip_graph,
                          fused_bn_stats=False if self.deterministic else None)
       else:

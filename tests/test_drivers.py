@@ -181,3 +181,15 @@ def test_cifar_real_data_native_end_to_end(tmp_path):
   from distributed_tensorflow_amd.checkpoint import keras_h5
   w = keras_h5.read_weights(str(tmp_path / "export" / "resnet56.h5"))
   assert w["conv1/kernel"].shape == (3, 3, 3, 16) and np.isfinite(w["fc10/kernel"]).all()
+
+
+@pytest.mark.gpu
+def test_imagenet_fp16_flag_runs_native_engine_with_loss_scale(tmp_path, small_validation):
+  """`--dtype fp16` (the reference's mixed-precision recipe, static loss scale 128) runs on
+  the native engine: the scale is applied to the loss gradient and removed in the optimizer."""
+  resnet_imagenet_main.define_imagenet_keras_flags()
+  stats = integration.run_synthetic(
+      main=resnet_imagenet_main.run, tmp_root=str(tmp_path),
+      extra_flags=["-batch_size", "16", "-train_steps", "4", "-num_gpus", "1", "-dtype", "fp16",
+                   "-distribution_strategy", "off", "-log_steps", "1"], max_train=None)
+  assert 0 < stats["loss"] < 20
