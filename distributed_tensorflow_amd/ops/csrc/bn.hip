@@ -25,6 +25,7 @@
 //
 // All kernels are bandwidth bound: every thread moves 16 bytes (8 channels) per access, a row
 // of C channels is covered by C/8 consecutive lanes, and a block walks rows grid-strided.
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -34,7 +35,16 @@
 namespace {
 
 constexpr int TPB = 256;
-constexpr int MAX_PARTIAL_BLOCKS = 1024;   // rows of the partial-sum workspace
+
+// 8 consecutive per-channel constants with two 16-byte loads (the per-thread prologues used to
+// issue up to 40 dependent 4-byte loads, which cost more than the sweep on short grids).
+__device__ __forceinline__ void load8(const float* __restrict__ p, float (&v)[8]) {
+  const f32x4 lo = *reinterpret_cast<const f32x4*>(p);
+  const f32x4 hi = *reinterpret_cast<const f32x4*>(p + 4);
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+}
+constexpr int MAX_PARTIAL_BLOCKS = 512;   // rows of the partial-sum workspace
 
 // Per-block partial sums: threads that own the same channel chunk (same tid % tpr) are summed
 // through LDS and the block writes one row [NV/8 quantities][C] of the workspace with plain
@@ -198,52 +208,71 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
   const int C = a.C, tpr = C >> 3, rpb = TPB / tpr;
   const int chunk = threadIdx.x % tpr, rowid = threadIdx.x / tpr;
   float scale[8], shift[8];
+  if (a.scale) {
+    load8(a.scale + chunk * 8, scale);
+    load8(a.shift + chunk * 8, shift);
+  } else {
+    float g[8], b[8], m[8], v[8];
+    load8(a.gamma + chunk * 8, g);
+    load8(a.beta + chunk * 8, b);
+    load8(a.mm + chunk * 8, m);
+    load8(a.mv + chunk * 8, v);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const int ch = chunk * 8 + c;
-    if (a.scale) {
-      scale[c] = a.scale[ch];
-      shift[c] = a.shift[ch];
-    } else {
-      const float invstd = rsqrtf(a.mv[ch] + a.eps);
-      scale[c] = a.gamma[ch] * invstd;
-      shift[c] = a.beta[ch] - a.mm[ch] * scale[c];
+    for (int c = 0; c < 8; ++c) {
+      scale[c] = g[c] * rsqrtf(v[c] + a.eps);
+      shift[c] = b[c] - m[c] * scale[c];
     }
   }
-  // The trip count is uniform per block (row0 is the block's first row of the pass) so that
-  // the four lanes of a quad can merge their mask bytes into one 32-bit store: the byte of
-  // thread t in this pass sits at  row0 * tpr + t,  and row0 * tpr is a multiple of 256.
-  for (int row0 = blockIdx.x * rpb; row0 < a.P; row0 += gridDim.x * rpb) {
-    const int row = row0 + rowid;
-    const bool valid = row < a.P;
-    const size_t off = (size_t)row * C + chunk * 8;
-    float f[8];
-    uint32_t bits = 0;
-    if (valid) {
-      unpack8(*reinterpret_cast<const u32x4*>(a.y + off), f);
+  // The trip count is uniform per block (row0 is the block's first row of a pass) so that the
+  // four lanes of a quad can merge their mask bytes into one 32-bit store: the byte of thread
+  // t in a pass sits at  row0 * tpr + t,  and row0 * tpr is a multiple of 256.  Four passes
+  // are loaded before any is used: with one 16-byte load per thread in flight the sweep is
+  // latency bound at about half of what the memory system delivers.
+  constexpr int U = 4;
+  const int stride = gridDim.x * rpb;
+  for (int row0 = blockIdx.x * rpb; row0 < a.P; row0 += U * stride) {
+    u32x4 yq[U], rq[U];
+    bool valid[U];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) f[c] = f[c] * scale[c] + shift[c];
-      if (a.res) {
-        float r[8];
-        unpack8(*reinterpret_cast<const u32x4*>(a.res + off), r);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) f[c] += r[c];
-      }
-      if (a.relu) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          bits |= (f[c] > 0.f ? 1u : 0u) << c;
-          f[c] = fmaxf(f[c], 0.f);
-        }
-      }
-      *reinterpret_cast<u32x4*>(a.z + off) = pack8(f);
+    for (int u = 0; u < U; ++u) {
+      const int row = row0 + u * stride + rowid;
+      valid[u] = row < a.P;
+      const size_t off = (size_t)row * C + chunk * 8;
+      yq[u] = valid[u] ? *reinterpret_cast<const u32x4*>(a.y + off) : u32x4{0, 0, 0, 0};
+      rq[u] = (valid[u] && a.res) ? *reinterpret_cast<const u32x4*>(a.res + off) : u32x4{0, 0, 0, 0};
     }
-    if (a.relu && a.mask) {
-      uint32_t w = bits << (8 * (threadIdx.x & 3));
-      w |= __shfl_xor(w, 1);
-      w |= __shfl_xor(w, 2);
-      if ((threadIdx.x & 3) == 0 && valid)
-        *reinterpret_cast<uint32_t*>(a.mask + (size_t)row0 * tpr + threadIdx.x) = w;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int prow0 = row0 + u * stride;
+      const size_t off = (size_t)(prow0 + rowid) * C + chunk * 8;
+      float f[8];
+      uint32_t bits = 0;
+      if (valid[u]) {
+        unpack8(yq[u], f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) f[c] = f[c] * scale[c] + shift[c];
+        if (a.res) {
+          float r[8];
+          unpack8(rq[u], r);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) f[c] += r[c];
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            bits |= (f[c] > 0.f ? 1u : 0u) << c;
+            f[c] = fmaxf(f[c], 0.f);
+          }
+        }
+        *reinterpret_cast<u32x4*>(a.z + off) = pack8(f);
+      }
+      if (a.relu && a.mask && prow0 < a.P) {         // block-uniform condition
+        uint32_t w = bits << (8 * (threadIdx.x & 3));
+        w |= __shfl_xor(w, 1);
+        w |= __shfl_xor(w, 2);
+        if ((threadIdx.x & 3) == 0 && valid[u])
+          *reinterpret_cast<uint32_t*>(a.mask + (size_t)prow0 * tpr + threadIdx.x) = w;
+      }
     }
   }
 }
@@ -263,11 +292,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
   const int C = a.C, tpr = C >> 3, rpb = TPB / tpr;
   const int chunk = threadIdx.x % tpr, rowid = threadIdx.x / tpr;
   float mean[8], invstd[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    mean[c] = a.mean[chunk * 8 + c];
-    invstd[c] = a.invstd[chunk * 8 + c];
-  }
+  load8(a.mean + chunk * 8, mean);
+  load8(a.invstd + chunk * 8, invstd);
   float part[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) part[i] = 0.f;
@@ -334,14 +360,16 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   const int chunk = threadIdx.x % tpr, rowid = threadIdx.x / tpr;
   const float invP = 1.f / (float)a.P;
   float mean[8], invstd[8], scale[8], c1[8], c2[8];
+  load8(a.mean + chunk * 8, mean);
+  load8(a.invstd + chunk * 8, invstd);
+  load8(a.gamma + chunk * 8, scale);
+  load8(a.dbeta + chunk * 8, c1);
+  load8(a.dgamma + chunk * 8, c2);
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    const int ch = chunk * 8 + c;
-    mean[c] = a.mean[ch];
-    invstd[c] = a.invstd[ch];
-    scale[c] = a.gamma[ch] * invstd[c];
-    c1[c] = a.dbeta[ch] * invP;
-    c2[c] = a.dgamma[ch] * invP;
+    scale[c] *= invstd[c];
+    c1[c] *= invP;
+    c2[c] *= invP;
   }
   const int mode = a.mask ? 2 : (a.z ? 1 : 0);
   auto finish = [&](const u32x4& gv, const u32x4& yq, const u32x4& zq, uint32_t bits, size_t off) {
@@ -368,12 +396,12 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   };
   const int stride = gridDim.x * rpb;
   int row = blockIdx.x * rpb + rowid;
-  for (; row + stride < a.P; row += 2 * stride) {          // two rows of loads in flight
-    u32x4 gv[2], yq[2], zq[2];
-    uint32_t bits[2];
-    size_t off[2];
+  for (; row + 3 * stride < a.P; row += 4 * stride) {      // four rows of loads in flight
+    u32x4 gv[4], yq[4], zq[4];
+    uint32_t bits[4];
+    size_t off[4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < 4; ++u) {
       off[u] = (size_t)(row + u * stride) * C + chunk * 8;
       gv[u] = *reinterpret_cast<const u32x4*>(a.dz + off[u]);
       yq[u] = *reinterpret_cast<const u32x4*>(a.y + off[u]);
@@ -381,7 +409,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
       bits[u] = mode == 2 ? a.mask[(size_t)(row + u * stride) * tpr + chunk] : 0u;
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) finish(gv[u], yq[u], zq[u], bits[u], off[u]);
+    for (int u = 0; u < 4; ++u) finish(gv[u], yq[u], zq[u], bits[u], off[u]);
   }
   for (; row < a.P; row += stride) {
     const size_t off = (size_t)row * C + chunk * 8;
@@ -414,9 +442,13 @@ void check_channels(int C, int P) {
 }
 
 int rows_grid(int P, int C) {
+  static const int cap = [] {
+    const char* e = std::getenv("DTF_BN_GRID_CAP");
+    return e ? std::atoi(e) : 512;
+  }();
   const int rpb = TPB / (C / 8);
   const int blocks = (P + rpb - 1) / rpb;
-  return blocks < 2048 ? blocks : 2048;
+  return blocks < cap ? blocks : cap;
 }
 
 // Reduction grid: enough blocks to pull full HBM bandwidth, at least 8 row passes per block,
