@@ -49,6 +49,9 @@ def main() -> int:
   ap.add_argument("--num_packs", type=int, default=4, help="gradient fusion buckets")
   ap.add_argument("--all_reduce_alg", default=None)
   ap.add_argument("--no_graph", action="store_true")
+  ap.add_argument("--rehearse_collectives", action="store_true",
+                  help="1 GPU only: run the multi-GPU code path (segmented backward, one RCCL "
+                       "all-reduce per bucket on the communication stream) in a one-rank group")
   ap.add_argument("--executor", default="hip", choices=["hip", "torch"])
   a = ap.parse_args()
   if os.environ.get("DTF_DEBUG_HANG"):      # dump every thread's stack if still running after N s
@@ -76,7 +79,9 @@ def main() -> int:
     sys.stderr.write("bench.py needs a GPU\n")
     return 2
 
-  if a.gpus > 1:
+  if a.gpus == 1 and a.rehearse_collectives:
+    os.environ["DTF_REHEARSE_COLLECTIVES"] = "1"
+  if a.gpus > 1 or a.rehearse_collectives:
     strat = strategy_lib.MirroredStrategy(use_gpu=True, all_reduce_alg=a.all_reduce_alg,
                                           num_packs=a.num_packs)
     device = strat.device
@@ -150,7 +155,9 @@ def main() -> int:
         "config": {"model": "resnet50_v1.5" if a.model == "resnet50" else a.model,
                    "global_batch": global_batch, "per_gpu_batch": a.batch,
                    "image": "%dx%dx%d" % shape, "classes": classes,
-                   "optimizer": "sgd_momentum_l2", "parallelism": "dp%d" % a.gpus,
+                   "optimizer": "sgd_momentum_l2", "parallelism": "dp%d" % a.gpus + (
+                       " (one-rank collective rehearsal)" if a.rehearse_collectives and a.gpus == 1
+                       else ""),
                    "executor": model.executor_kind, "final_loss": round(loss_val, 4),
                    "baseline_img_per_sec": baseline_for(a.gpus)}}
     print(json.dumps(out), flush=True)

@@ -60,7 +60,7 @@ class GradientReducer:
     return self.store.grads[b.start:b.end]
 
   def on_bucket_ready(self, b: Bucket):
-    if self.n <= 1:
+    if self.n <= 1 and not getattr(self.comm, "rehearse", False):
       return
     g = self._slice(b)
     c = self.comm

@@ -40,11 +40,18 @@ class Communicator:
     self.world_size = task.world_size
     self._owns_group = owns_group
     self._groups = {}
+    # Rehearsal: a one-rank process group whose collectives are really issued (see
+    # `get_communicator`), so the stream / event choreography of the multi-GPU path can be
+    # exercised and timed on a single GPU.
+    self.rehearse = False
+
+  def _single(self) -> bool:
+    return self.world_size == 1 and not self.rehearse
 
   # -- collectives -----------------------------------------------------------------
   def all_reduce(self, t: torch.Tensor, average: bool = False, async_op: bool = False,
                  group=None):
-    if self.world_size == 1:
+    if self._single():
       return None
     w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op, group=group)
     if average:
@@ -54,12 +61,12 @@ class Communicator:
     return w
 
   def reduce(self, t: torch.Tensor, dst: int = 0, async_op: bool = False, group=None):
-    if self.world_size == 1:
+    if self._single():
       return None
     return dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, async_op=async_op, group=group)
 
   def broadcast(self, t: torch.Tensor, root: int = 0, async_op: bool = False, group=None):
-    if self.world_size == 1:
+    if self._single():
       return None
     return dist.broadcast(t, src=root, async_op=async_op, group=group)
 
@@ -86,7 +93,7 @@ class Communicator:
     return dist.irecv(t, src)
 
   def barrier(self, group=None):
-    if self.world_size > 1:
+    if not self._single():
       if self.backend == "nccl":
         dist.barrier(group=group, device_ids=[self.device.index])
       else:
@@ -150,7 +157,18 @@ def get_communicator(task: Optional[TaskInfo] = None, use_gpu: bool = True,
     owns = True
   elif dist.is_initialized():
     backend = dist.get_backend()
+  rehearse = False
+  if task.world_size == 1 and os.environ.get("DTF_REHEARSE_COLLECTIVES") == "1" \
+      and not dist.is_initialized():
+    # one-rank group over a private file store: every collective is issued for real
+    import tempfile  # pylint: disable=import-outside-toplevel
+    path = os.path.join(tempfile.mkdtemp(prefix="dtf_store_"), "store")
+    kwargs = {"device_id": device} if backend == "nccl" else {}
+    dist.init_process_group(backend, store=dist.FileStore(path, 1), rank=0, world_size=1,
+                            timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
+    owns = rehearse = True
   _COMM = Communicator(task, device, backend, owns)
+  _COMM.rehearse = rehearse
   return _COMM
 
 

@@ -132,12 +132,12 @@ class MirroredStrategy(Strategy):
     return self.comm.rank == 0
 
   def make_reducer(self, store, buckets):
-    if self.comm.world_size <= 1:
+    if self.comm.world_size <= 1 and not self.comm.rehearse:
       return None
     return GradientReducer(self.comm, store, buckets, self.all_reduce_alg)
 
   def broadcast_variables(self, store, root: int = 0):
-    if self.comm.world_size <= 1:
+    if self.comm.world_size <= 1 and not self.comm.rehearse:
       return
     self.comm.broadcast(store.params, root)
     self.comm.broadcast(store.state, root)
@@ -146,7 +146,7 @@ class MirroredStrategy(Strategy):
     store.version += 1
 
   def reduce_scalars(self, t):
-    if self.comm.world_size > 1:
+    if self.comm.world_size > 1 or self.comm.rehearse:
       self.comm.all_reduce(t)
     return t
 

@@ -59,3 +59,31 @@ def test_two_ranks_native_executor_with_overlapped_allreduce(tmp_path):
   assert r[0]["psum"] == pytest.approx(r[1]["psum"], rel=1e-5)
   assert r[0]["ncoll"] == 4 * 3
   assert r[0]["losses"][-1] < r[0]["losses"][0]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("alg", [None, "ring", "hierarchical_copy"])
+def test_one_rank_rccl_rehearsal_of_the_overlapped_reducer(tmp_path, alg):
+  """The multi-GPU step (segmented backward, per-bucket RCCL collective on the communication
+  stream, optimizer ordered after it) in a one-rank RCCL group on the GPU: real `nccl` backend
+  calls, real stream hand-offs, and the same trajectory as the plain single-GPU step."""
+  import subprocess, json
+  if torch.cuda.is_initialized():
+    pytest.skip("the GPU is already initialised in this process; child programs cannot be started")
+  sys.path.insert(0, os.path.join(ROOT, "tests"))
+  from test_distributed import _rehearsal_script
+  script = _rehearsal_script(tmp_path, "cuda", "bf16", alg)
+  env = dict(os.environ)
+  for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TF_CONFIG", "DTF_BACKEND"):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True,
+                     timeout=360)
+  assert r.returncode == 0, r.stderr[-3000:]
+  out = json.loads((tmp_path / "out.json").read_text())
+  assert out["rehearsed"]["backend"] == "nccl"
+  per_bucket = 1 if alg is None else 2
+  assert out["rehearsed"]["ncoll"] == 5 * 3 * per_bucket
+  # fp32 atomics make the two runs differ in the last bits only
+  assert out["rehearsed"]["losses"] == pytest.approx(out["plain"]["losses"], rel=2e-2)
+  assert out["rehearsed"]["losses"][-1] < out["rehearsed"]["losses"][0]

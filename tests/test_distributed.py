@@ -281,3 +281,50 @@ time.sleep(60)
   code = launch.launch([str(script)], 2, log_dir=str(tmp_path / "logs"))
   assert code == 3
   assert time.time() - t0 < 30          # the surviving rank was torn down, not waited for
+
+
+def _rehearsal_script(tmp_path, device: str, dtype: str, alg):
+  script = tmp_path / "rehearse.py"
+  script.write_text("import sys, os, json\nsys.path.insert(0, %r)\nimport torch\n" % ROOT + textwrap.dedent("""
+    import faulthandler
+    faulthandler.dump_traceback_later(240, exit=True)
+    os.environ["DTF_REHEARSE_COLLECTIVES"] = "1"
+    from distributed_tensorflow_amd import models
+    from distributed_tensorflow_amd.parallel import strategy as S
+    from distributed_tensorflow_amd.train.model import Model
+    from distributed_tensorflow_amd.train.optimizers import SGD
+    dev = torch.device(%r)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(16, 32, 32, 3, generator=g) * 50 + 100).to(dev)
+    y = torch.randint(0, 10, (16, 1), generator=g).float().to(dev)
+    out = {}
+    for name, strat in (("plain", None),
+                        ("rehearsed", S.MirroredStrategy(use_gpu=dev.type == "cuda", num_packs=3,
+                                                         all_reduce_alg=%r))):
+      m = Model(models.resnet20(), strategy=strat, dtype=%r, device=dev, seed=1)
+      m.compile(SGD(0.05, momentum=0.9), "sparse_categorical_crossentropy")
+      losses = [m.train_on_batch(x, y)[0].item() for _ in range(5)]
+      red = m._grad_reducer()
+      out[name] = {"losses": losses, "psum": m.store.params.double().sum().item(),
+                   "ncoll": red.collectives_launched if red is not None else 0,
+                   "backend": strat.comm.backend if strat is not None else None}
+    json.dump(out, open(%r, "w"))
+  """ % (device, alg, dtype, str(tmp_path / "out.json"))))
+  return script
+
+
+def test_one_rank_collective_rehearsal_issues_real_collectives(tmp_path):
+  """`DTF_REHEARSE_COLLECTIVES=1` forms a one-rank group and runs the segmented backward +
+  per-bucket all-reduce path; the result equals training without a strategy."""
+  script = _rehearsal_script(tmp_path, "cpu", "fp32", "ring")
+  env = dict(os.environ)
+  for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TF_CONFIG"):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True,
+                     timeout=300)
+  assert r.returncode == 0, r.stderr[-3000:]
+  out = json.loads((tmp_path / "out.json").read_text())
+  assert out["rehearsed"]["backend"] == "gloo"
+  assert out["rehearsed"]["ncoll"] == 5 * 3 and out["plain"]["ncoll"] == 0
+  assert out["rehearsed"]["losses"] == pytest.approx(out["plain"]["losses"], rel=1e-5)
+  assert out["rehearsed"]["psum"] == pytest.approx(out["plain"]["psum"], rel=1e-7)
