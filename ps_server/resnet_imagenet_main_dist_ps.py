@@ -53,6 +53,22 @@ def define_flags():
                           worker_hosts="localhost:1112", task_type="worker", task_index=0)
 
 
+def run_numbered(k: int, num_workers: int = 15):
+  """Entry point of the per-process files `resnet_imagenet_main_dist_ps_<k>.py`: process k of a
+  1 ps + `num_workers` workers job whose addresses come from `DTF_PS_HOSTS` /
+  `DTF_WORKER_HOSTS` (default: consecutive ports from 1111 on this machine)."""
+  logging.set_verbosity(logging.INFO)
+  define_flags()
+  ps = os.environ.get("DTF_PS_HOSTS", "localhost:1111")
+  workers = os.environ.get("DTF_WORKER_HOSTS") or ",".join(
+      "localhost:%d" % (1112 + i) for i in range(num_workers))
+  os.environ.setdefault("DTF_GPUS_PER_HOST", "4")        # the reference pins GPU k mod 4
+  sys.argv = _apply_proc_index(
+      [sys.argv[0], "--proc_index", str(k), "--ps_hosts", ps, "--worker_hosts", workers]
+      + sys.argv[1:])
+  flags_core.run(main)
+
+
 if __name__ == "__main__":
   logging.set_verbosity(logging.INFO)
   define_flags()

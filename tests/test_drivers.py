@@ -154,6 +154,35 @@ def test_parameter_server_variant_driver_on_localhost(tmp_path):
   assert "'loss'" in outs[1] and "Run stats" in outs[0]
 
 
+def test_numbered_parameter_server_entry_points(tmp_path):
+  """`resnet_cifar_main_dist_ps_remote_{0,1}.py` (role fixed by the file name, addresses from
+  the environment) and the numbered ImageNet files `ps_server/..._ps_{0,1}.py` in a 1 ps +
+  1 worker job with the trivial model."""
+  import subprocess
+  p0, p1 = _free_ports(2)
+  args = ["--use_synthetic_data", "--num_gpus", "0", "--batch_size", "8", "--train_steps", "2",
+          "--skip_eval"]
+  os.environ["DTF_PS_HOST"], os.environ["DTF_WORKER_HOST"] = "localhost:%d" % p0, "localhost:%d" % p1
+  try:
+    outs = _run_pair(tmp_path, [
+        [os.path.join(ROOT, "resnet_cifar_main_dist_ps_remote_0.py")] + args,
+        [os.path.join(ROOT, "resnet_cifar_main_dist_ps_remote_1.py")] + args])
+  finally:
+    del os.environ["DTF_PS_HOST"], os.environ["DTF_WORKER_HOST"]
+  assert "'loss'" in outs[1] and "Run stats" in outs[0]
+  p0, p1 = _free_ports(2)
+  os.environ["DTF_PS_HOSTS"], os.environ["DTF_WORKER_HOSTS"] = "localhost:%d" % p0, "localhost:%d" % p1
+  try:
+    outs = _run_pair(tmp_path, [
+        [os.path.join(ROOT, "ps_server", "resnet_imagenet_main_dist_ps_%d.py" % k)] + args +
+        ["--use_trivial_model"] for k in (0, 1)])
+  finally:
+    del os.environ["DTF_PS_HOSTS"], os.environ["DTF_WORKER_HOSTS"]
+  assert "'loss'" in outs[1] and "Run stats" in outs[0]
+  for k in range(16):
+    assert os.path.exists(os.path.join(ROOT, "ps_server", "resnet_imagenet_main_dist_ps_%d.py" % k))
+
+
 @pytest.mark.gpu
 def test_cifar_real_data_native_end_to_end(tmp_path):
   """CIFAR driver on record files: C++ loader -> device prefetcher -> native executor, with
