@@ -141,6 +141,8 @@ def main() -> int:
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     dt = float(t.item())
   loss_val = float(last[0].item())
+  ex = next(iter(model._executors.values()))  # pylint: disable=protected-access
+  launch_mode = {True: "hipgraph", False: "eager"}.get(getattr(ex, "use_graph", False), "auto")
   if rank == 0:
     value = global_batch * a.steps / dt
     out = {
@@ -158,7 +160,8 @@ def main() -> int:
                    "optimizer": "sgd_momentum_l2", "parallelism": "dp%d" % a.gpus + (
                        " (one-rank collective rehearsal)" if a.rehearse_collectives and a.gpus == 1
                        else ""),
-                   "executor": model.executor_kind, "final_loss": round(loss_val, 4),
+                   "executor": model.executor_kind, "launch": launch_mode,
+                   "final_loss": round(loss_val, 4),
                    "baseline_img_per_sec": baseline_for(a.gpus)}}
     print(json.dumps(out), flush=True)
   if strat is not None:

@@ -539,28 +539,32 @@ class HipExecutor:
       self._ensure_packed()
       self._stage(images, labels)
       self._set_loss_scale(loss_scale)
-      if on_bucket_ready is None and self.use_graph is None:
-        self._calibrate_step()
-      elif on_bucket_ready is None and self.use_graph:
-        self._run_train_graph()
+      if self.use_graph is None:
+        self._calibrate_step(on_bucket_ready)
+      elif self.use_graph:
+        self._run_train_graph(on_bucket_ready)
       else:
-        s = native.stream_handle(self.device)
-        self.fwd_plan.run(0, self.fwd_plan.size(), s)
-        for begin, end, ready in self._segments:
-          self.bwd_plan.run(begin, end, s)
-          if on_bucket_ready is not None:
-            for b in ready:
-              on_bucket_ready(b)
+        self._run_eager(on_bucket_ready)
       out = self.accum.clone()
     return out[0] / self.N, out[1]
 
-  def _run_eager(self):
+  def _run_eager(self, on_bucket_ready=None):
     s = native.stream_handle(self.device)
     self.fwd_plan.run(0, self.fwd_plan.size(), s)
-    self.bwd_plan.run(0, self.bwd_plan.size(), s)
+    if on_bucket_ready is None:
+      self.bwd_plan.run(0, self.bwd_plan.size(), s)
+      return
+    for begin, end, ready in self._segments:
+      self.bwd_plan.run(begin, end, s)
+      for b in ready:
+        on_bucket_ready(b)
 
-  def _calibrate_step(self):
-    """Auto mode: steps 0-3 eager (2-3 timed), step 4 captures, steps 5-7 replay (6-7 timed)."""
+  def _calibrate_step(self, on_bucket_ready=None):
+    """Auto mode: steps 0-3 eager (2-3 timed), step 4 captures, steps 5-7 replay (6-7 timed).
+
+    With a gradient reducer the timed region contains the launch of the bucket collectives;
+    every rank runs the same sequence of modes, and ranks that end up with different choices
+    still issue identical collectives (the mode only changes how kernels are enqueued)."""
     i = self._calib_step
     self._calib_step += 1
     mode = "eager" if i < 4 else "graph"
@@ -570,9 +574,9 @@ class HipExecutor:
       t1 = torch.cuda.Event(enable_timing=True)
       t0.record()
     if mode == "eager":
-      self._run_eager()
+      self._run_eager(on_bucket_ready)
     else:
-      self._run_train_graph()
+      self._run_train_graph(on_bucket_ready)
     if timed:
       t1.record()
       self._calib[mode].append((t0, t1))
@@ -585,8 +589,10 @@ class HipExecutor:
                    "graph" if self.use_graph else "eager")
       self._calib = {}
 
-  def _run_train_graph(self):
-    """Forward + backward as one hipGraph (captured at first use on a side stream)."""
+  def _run_train_graph(self, on_bucket_ready=None):
+    """Forward and backward as hipGraphs (captured at first use on a side stream): one graph for
+    the forward plan and one per backward segment, so that a gradient reducer can start a
+    bucket's collective between two replays exactly as in the eager path."""
     cur = torch.cuda.current_stream(self.device)
     if self._train_graph is None:
       if self._graph_stream is None:
@@ -600,15 +606,24 @@ class HipExecutor:
         self.bwd_plan.run(0, self.bwd_plan.size(), s)
         gs.synchronize()
         h1 = self.fwd_plan.capture(0, self.fwd_plan.size(), s)
-        h2 = self.bwd_plan.capture(0, self.bwd_plan.size(), s)
-        self._train_graph = (h1, h2)
+        hs = [self.bwd_plan.capture(b, e, s) for b, e, _ in self._segments]
+        self._train_graph = (h1, hs)
       cur.wait_stream(gs)
-      # The eager run above updated the BatchNorm moving averages once; it is the first
-      # training step's forward, so fall through to replay only from the next call on.
+      # The eager run above updated the BatchNorm moving averages once and left complete
+      # gradients; it is this training step's forward + backward, so only the collectives
+      # remain to be issued.  Replay starts with the next call.
+      if on_bucket_ready is not None:
+        for _b, _e, ready in self._segments:
+          for b in ready:
+            on_bucket_ready(b)
       return
     s = int(cur.cuda_stream)
     self.fwd_plan.replay(self._train_graph[0], s)
-    self.bwd_plan.replay(self._train_graph[1], s)
+    for h, (_b, _e, ready) in zip(self._train_graph[1], self._segments):
+      self.bwd_plan.replay(h, s)
+      if on_bucket_ready is not None:
+        for b in ready:
+          on_bucket_ready(b)
 
   @torch.no_grad()
   def eval_step(self, images: torch.Tensor, labels: torch.Tensor):

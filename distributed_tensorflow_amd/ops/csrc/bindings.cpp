@@ -256,8 +256,97 @@ void check_launch() {
   if (e != hipSuccess) throw std::runtime_error(std::string("kernel launch failed: ") + hipGetErrorString(e));
 }
 
+// ---- streams that really run next to each other ------------------------------------------------
+// HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, round-robin at stream
+// creation).  Two streams that land on the same queue execute strictly in submission order:
+// a side lane created after a communication library has taken its streams was measured to
+// share the main stream's queue, which turned the overlapped step (23.2 ms) into a serial one
+// with extra event traffic (24.4 ms).  So a lane is not just created, it is *probed*: a short
+// spin kernel runs on the main stream and on the candidate at the same time, and the candidate
+// is kept only if the pair takes about one spin, not two.
+__global__ void spin_kernel(unsigned long long ticks, unsigned int* sink) {
+  const unsigned long long t0 = wall_clock64();
+  unsigned int it = 0;
+  while (wall_clock64() - t0 < ticks && it < (1u << 20)) ++it;     // bounded: always exits
+  if (sink != nullptr && it == 0xffffffffu) *sink = it;
+}
+
+class LaneRegistry {
+ public:
+  // A stream that executes concurrently with `main` and with every lane handed out before.
+  // Lanes live as long as the process.
+  hipStream_t pick(hipStream_t main, int priority) {
+    std::vector<hipStream_t> peers(lanes_);
+    peers.push_back(main);
+    std::vector<hipStream_t> rejected;
+    hipStream_t chosen = nullptr;
+    last_probe_.clear();
+    for (int attempt = 0; attempt < 12 && !chosen; ++attempt) {
+      hipStream_t c = nullptr;
+      HIP_CHECK(hipStreamCreateWithPriority(&c, hipStreamNonBlocking, priority));
+      bool ok = true;
+      for (hipStream_t peer : peers) {
+        const float ratio = overlap_ratio(peer, c);
+        last_probe_.push_back(ratio);
+        if (ratio > 1.5f) { ok = false; break; }
+      }
+      if (ok) chosen = c; else rejected.push_back(c);
+    }
+    if (!chosen) {                       // every candidate shares a queue with someone: keep one
+      chosen = rejected.back();
+      rejected.pop_back();
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    lanes_.push_back(chosen);
+    return chosen;
+  }
+  const std::vector<float>& last_probe() const { return last_probe_; }
+
+ private:
+  // (time of two simultaneous spins) / (time of one): ~1 when concurrent, ~2 when serialised.
+  static float overlap_ratio(hipStream_t a, hipStream_t b) {
+    int dev = 0, khz = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+    if (khz <= 0) khz = 100000;
+    const float spin_ms = 0.25f;
+    const unsigned long long ticks = (unsigned long long)(spin_ms * (float)khz);
+    hipEvent_t e0, ea, eb;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&ea));
+    HIP_CHECK(hipEventCreate(&eb));
+    float worst = 0.f;
+    for (int trial = 0; trial < 2; ++trial) {
+      HIP_CHECK(hipEventRecord(e0, a));
+      HIP_CHECK(hipStreamWaitEvent(b, e0, 0));
+      hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, ticks, (unsigned int*)nullptr);
+      hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, ticks, (unsigned int*)nullptr);
+      HIP_CHECK(hipEventRecord(ea, a));
+      HIP_CHECK(hipEventRecord(eb, b));
+      HIP_CHECK(hipEventSynchronize(ea));
+      HIP_CHECK(hipEventSynchronize(eb));
+      float ta = 0.f, tb = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&ta, e0, ea));
+      HIP_CHECK(hipEventElapsedTime(&tb, e0, eb));
+      const float r = (ta > tb ? ta : tb) / spin_ms;
+      if (trial == 0 || r < worst) worst = r;      // best of two: a probe can be delayed, never sped up
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    return worst;
+  }
+  std::vector<hipStream_t> lanes_;
+  std::vector<float> last_probe_;
+};
+
+LaneRegistry& lane_registry() {
+  static LaneRegistry r;
+  return r;
+}
+
 // A plan has two lanes.  Lane 0 is the caller's stream; lane 1 is a side stream owned by the
-// plan, used for work that is independent of the main dependency chain (weight gradients next to
+// process (shared by all plans, chosen by LaneRegistry), used for work that is independent of the main dependency chain (weight gradients next to
 // the BatchNorm / data-gradient chain of the backward pass: atomics- and MFMA-bound kernels
 // next to bandwidth-bound ones).  "fork" makes the side lane wait for everything enqueued on
 // the main lane so far, "join" makes the main lane wait for the side lane.  Under stream capture
@@ -270,7 +359,6 @@ class Plan {
       if (g.graph) (void)hipGraphDestroy(g.graph);
     }
     for (auto e : events_) (void)hipEventDestroy(e);
-    if (side_) (void)hipStreamDestroy(side_);
   }
   int add(const std::string& kind, const py::dict& args, const std::string& name, int lane) {
     if (lane != 0 && lane != 1) throw std::invalid_argument("Plan.add: lane must be 0 or 1");
@@ -331,7 +419,12 @@ class Plan {
   };
   struct Graph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
 
-  hipStream_t side() {
+  static hipStream_t& shared_side() {
+    static hipStream_t s = nullptr;
+    return s;
+  }
+  hipStream_t side(hipStream_t main) {
+    hipStream_t& side_ = shared_side();
     if (!side_) {
       // DTF_SIDE_PRIORITY: "low" / "high" place the side lane below / above the main lane
       int lo = 0, hi = 0;
@@ -340,7 +433,12 @@ class Plan {
       int prio = 0;
       if (e && std::string(e) == "low") prio = lo;
       if (e && std::string(e) == "high") prio = hi;
-      HIP_CHECK(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, prio));
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      HIP_CHECK(hipStreamIsCapturing(main, &cs));
+      if (cs == hipStreamCaptureStatusNone && !std::getenv("DTF_NO_LANE_PROBE"))
+        side_ = lane_registry().pick(main, prio);
+      else                                   // no synchronisation is allowed under capture
+        HIP_CHECK(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, prio));
     }
     return side_;
   }
@@ -350,15 +448,15 @@ class Plan {
       Entry& e = ops_[i];
       if (e.type == FORK) {
         HIP_CHECK(hipEventRecord(e.event, main));
-        HIP_CHECK(hipStreamWaitEvent(side(), e.event, 0));
+        HIP_CHECK(hipStreamWaitEvent(side(main), e.event, 0));
       } else if (e.type == JOIN) {
         if (side_busy) {
-          HIP_CHECK(hipEventRecord(e.event, side()));
+          HIP_CHECK(hipEventRecord(e.event, side(main)));
           HIP_CHECK(hipStreamWaitEvent(main, e.event, 0));
           side_busy = false;
         }
       } else if (e.lane == 1) {
-        e.launch(side());
+        e.launch(side(main));
         side_busy = true;
       } else {
         e.launch(main);
@@ -371,7 +469,6 @@ class Plan {
   std::vector<std::string> names_;
   std::vector<Graph> graphs_;
   std::vector<hipEvent_t> events_;
-  hipStream_t side_ = nullptr;
 };
 
 }  // namespace
@@ -382,6 +479,14 @@ PYBIND11_MODULE(_dtf_native, m) {
     make_op(kind, args)(reinterpret_cast<hipStream_t>(stream));
     check_launch();
   }, py::arg("kind"), py::arg("args"), py::arg("stream") = 0);
+  m.def("concurrent_stream", [](uintptr_t main, int priority) {
+    return reinterpret_cast<uintptr_t>(
+        lane_registry().pick(reinterpret_cast<hipStream_t>(main), priority));
+  }, py::arg("main"), py::arg("priority") = 0,
+        "A new stream probed to execute concurrently with `main` and every lane handed out "
+        "before (the plans' side lane included); lives as long as the process.");
+  m.def("last_lane_probe", []() { return lane_registry().last_probe(); },
+        "Overlap ratios measured by the most recent lane pick (1: concurrent, 2: serialised).");
   m.def("fastdiv_check", [](uint32_t n, uint32_t d) { return fd_div(n, make_fastdiv(d)); });
   m.def("pack_desc_size", []() { return (int)sizeof(PackDesc); });
   m.def("bn_workspace_floats", []() { return bn_workspace_floats(); });

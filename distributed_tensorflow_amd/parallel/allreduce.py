@@ -4,8 +4,8 @@ The executor calls `on_bucket_ready(bucket)` as soon as every gradient of a
 fusion bucket has been *enqueued* on the compute stream (buckets complete in
 reverse layer order).  Each call launches one asynchronous collective on the
 bucket's slice of the flat gradient buffer; with the RCCL backend the collective
-runs on the communication stream after an event recorded on the compute stream,
-so it overlaps the remaining backward kernels.  `finish()` makes the compute
+runs on a dedicated communication stream after an event recorded on the compute
+stream, so it overlaps the remaining backward kernels.  `finish()` makes the compute
 stream wait for all outstanding collectives before the optimizer runs.
 
 Algorithms (`--all_reduce_alg`, reference `resnet_imagenet_main.py:116-117`):
@@ -21,6 +21,7 @@ number of replicas is folded into the fused optimizer (`divisor`).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -31,6 +32,15 @@ from .comm import Communicator
 __all__ = ["GradientReducer", "ALL_REDUCE_ALGS"]
 
 ALL_REDUCE_ALGS = (None, "nccl", "rccl", "ring", "hierarchical_copy")
+
+
+def _priority_range(device):
+  """(least urgent, most urgent) HIP stream priorities of `device`."""
+  with torch.cuda.device(device):
+    try:
+      return torch.cuda.Stream.priority_range()
+    except Exception:  # pylint: disable=broad-except
+      return 0, -1
 
 
 class GradientReducer:
@@ -47,7 +57,8 @@ class GradientReducer:
     self.group = group
     self.n = group_size if group_size is not None else comm.world_size
     self._pending = []
-    self._scratch = {}
+    self._stream = None            # None: not decided yet; False: torch.distributed's own stream
+    self._stream_pending = False
     self.bytes_reduced = 0
     self.collectives_launched = 0
 
@@ -58,6 +69,52 @@ class GradientReducer:
 
   def _slice(self, b: Bucket) -> torch.Tensor:
     return self.store.grads[b.start:b.end]
+
+  def _own_stream(self, device) -> Optional["torch.cuda.Stream"]:
+    """The communication stream of the RCCL path: a stream probed (by the native extension) to
+    execute concurrently with the compute stream and the executor's side lane, i.e. sitting on
+    a hardware queue of its own.  A collective kernel that shared the compute stream's queue
+    would run in submission order with the backward kernels and hold them up while it waits
+    for its peers.  `DTF_COMM_STREAM=torch` leaves the choice to torch.distributed (its
+    internal stream, `async_op=True`)."""
+    if self._stream is None:
+      self._stream = False
+      if (self.comm.backend == "nccl" and device.type == "cuda"
+          and os.environ.get("DTF_COMM_STREAM", "own") != "torch"):
+        from ..ops import native  # pylint: disable=import-outside-toplevel
+        if native.available():
+          _lo, hi = _priority_range(device)
+          # Normal priority: a high-priority communication stream was seen to stall the first
+          # hipGraph replay that follows it (one-rank rehearsal on an MI355X); opt in with
+          # DTF_COMM_PRIORITY=high for eager-launch experiments.
+          prio = hi if os.environ.get("DTF_COMM_PRIORITY", "normal") == "high" else 0
+          cur = torch.cuda.current_stream(device)
+          h = native.ext().concurrent_stream(int(cur.cuda_stream), prio)
+          self._stream = torch.cuda.ExternalStream(h, device=device)
+    return self._stream or None
+
+  def _issue(self, g: torch.Tensor, async_op: bool):
+    """The bucket's collective(s); returns the last work handle (None for blocking calls)."""
+    c = self.comm
+    if self.alg == "ring" and c.supports_reduce_scatter() and g.numel() % self.n == 0:
+      shard = g.numel() // self.n
+      r = c.rank if self.group is None else torch.distributed.get_rank(self.group)
+      mine = g[r * shard:(r + 1) * shard]
+      w1 = c.reduce_scatter(mine, g, async_op=async_op, group=self.group)
+      if w1 is not None:
+        w1.wait()   # stream-ordered on the comm stream; no host block with RCCL
+      w2 = c.all_gather(g, mine, async_op=async_op, group=self.group)
+      self.collectives_launched += 2
+      return w2
+    if self.alg == "hierarchical_copy":
+      w1 = c.reduce(g, dst=0, async_op=async_op, group=self.group)
+      if w1 is not None:
+        w1.wait()
+      w2 = c.broadcast(g, root=0, async_op=async_op, group=self.group)
+      self.collectives_launched += 2
+      return w2
+    self.collectives_launched += 1
+    return c.all_reduce(g, async_op=async_op, group=self.group)
 
   def on_bucket_ready(self, b: Bucket):
     if self.n <= 1 and not getattr(self.comm, "rehearse", False):
@@ -72,24 +129,17 @@ class GradientReducer:
       # (it completes with GPU_MAX_HW_QUEUES=16).  gloo on GPU tensors is a test / rehearsal
       # configuration, so the overlap is given up there: drain the compute stream first.
       torch.cuda.current_stream(g.device).synchronize()
-    if self.alg == "ring" and c.supports_reduce_scatter() and g.numel() % self.n == 0:
-      shard = g.numel() // self.n
-      r = c.rank if self.group is None else torch.distributed.get_rank(self.group)
-      mine = g[r * shard:(r + 1) * shard]
-      w1 = c.reduce_scatter(mine, g, async_op=True, group=self.group)
-      w1.wait()   # stream-ordered on the comm stream; no host block with RCCL
-      w2 = c.all_gather(g, mine, async_op=True, group=self.group)
-      self._pending.append(w2)
-      self.collectives_launched += 2
-    elif self.alg == "hierarchical_copy":
-      w1 = c.reduce(g, dst=0, async_op=True, group=self.group)
-      w1.wait()
-      w2 = c.broadcast(g, root=0, async_op=True, group=self.group)
-      self._pending.append(w2)
-      self.collectives_launched += 2
+    cs = self._own_stream(g.device) if g.is_cuda else None
+    if cs is not None:
+      # stream-ordered, nothing blocks the host: the communication stream waits for the
+      # gradients enqueued so far, the collective is issued as a blocking-API call *on that
+      # stream*, and finish() makes the compute stream wait for the communication stream
+      cs.wait_stream(torch.cuda.current_stream(g.device))
+      with torch.cuda.stream(cs):
+        self._issue(g, async_op=False)
+      self._stream_pending = True
     else:
-      self._pending.append(c.all_reduce(g, async_op=True, group=self.group))
-      self.collectives_launched += 1
+      self._pending.append(self._issue(g, async_op=True))
 
   def finish(self):
     """Orders the optimizer after every outstanding collective."""
@@ -97,6 +147,9 @@ class GradientReducer:
       if w is not None:
         w.wait()
     self._pending = []
+    if self._stream_pending:
+      torch.cuda.current_stream(self._stream.device).wait_stream(self._stream)
+      self._stream_pending = False
 
   def reduce_all_now(self):
     """Non-overlapped path: reduce every bucket after backward has finished."""

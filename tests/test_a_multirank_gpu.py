@@ -83,7 +83,8 @@ def test_one_rank_rccl_rehearsal_of_the_overlapped_reducer(tmp_path, alg):
   out = json.loads((tmp_path / "out.json").read_text())
   assert out["rehearsed"]["backend"] == "nccl"
   per_bucket = 1 if alg is None else 2
-  assert out["rehearsed"]["ncoll"] == 5 * 3 * per_bucket
+  # 10 steps: eager launches, the capture step and hipGraph replays of the backward segments
+  assert out["rehearsed"]["ncoll"] == 10 * 3 * per_bucket
   # fp32 atomics make the two runs differ in the last bits only
-  assert out["rehearsed"]["losses"] == pytest.approx(out["plain"]["losses"], rel=2e-2)
+  assert out["rehearsed"]["losses"] == pytest.approx(out["plain"]["losses"], rel=5e-2)
   assert out["rehearsed"]["losses"][-1] < out["rehearsed"]["losses"][0]

@@ -303,7 +303,7 @@ def _rehearsal_script(tmp_path, device: str, dtype: str, alg):
                                                          all_reduce_alg=%r))):
       m = Model(models.resnet20(), strategy=strat, dtype=%r, device=dev, seed=1)
       m.compile(SGD(0.05, momentum=0.9), "sparse_categorical_crossentropy")
-      losses = [m.train_on_batch(x, y)[0].item() for _ in range(5)]
+      losses = [m.train_on_batch(x, y)[0].item() for _ in range(10)]
       red = m._grad_reducer()
       out[name] = {"losses": losses, "psum": m.store.params.double().sum().item(),
                    "ncoll": red.collectives_launched if red is not None else 0,
@@ -325,6 +325,6 @@ def test_one_rank_collective_rehearsal_issues_real_collectives(tmp_path):
   assert r.returncode == 0, r.stderr[-3000:]
   out = json.loads((tmp_path / "out.json").read_text())
   assert out["rehearsed"]["backend"] == "gloo"
-  assert out["rehearsed"]["ncoll"] == 5 * 3 and out["plain"]["ncoll"] == 0
+  assert out["rehearsed"]["ncoll"] == 10 * 3 and out["plain"]["ncoll"] == 0
   assert out["rehearsed"]["losses"] == pytest.approx(out["plain"]["losses"], rel=1e-5)
   assert out["rehearsed"]["psum"] == pytest.approx(out["plain"]["psum"], rel=1e-7)
