@@ -43,6 +43,9 @@ __all__ = ["HipExecutor", "supports"]
 
 def supports(spec: ModelSpec) -> bool:
   """True when every op of the model has a native kernel path."""
+  first = spec.ops[0] if spec.ops else None
+  if first is None or first.kind != "conv" or first.inputs[0] != "input":
+    return False          # the planner stages the input batch for a leading convolution
   for op in spec.ops:
     if op.kind not in ("conv", "bn", "maxpool", "mean", "dense"):
       return False

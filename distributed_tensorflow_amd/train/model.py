@@ -34,7 +34,8 @@ __all__ = ["Model", "SUPPORTED_LOSSES"]
 SUPPORTED_LOSSES = ("sparse_categorical_crossentropy", "categorical_crossentropy")
 
 
-def _pick_executor_kind(requested: str, device: torch.device, dtype: str) -> str:
+def _pick_executor_kind(requested: str, device: torch.device, dtype: str,
+                        spec: Optional[ModelSpec] = None) -> str:
   """auto: the native engine for 16-bit training on a GPU, PyTorch ops otherwise.
 
   The native engine's 16-bit format is bfloat16 (fp32 accumulation, fp32 master weights).
@@ -45,6 +46,13 @@ def _pick_executor_kind(requested: str, device: torch.device, dtype: str) -> str
   if requested != "auto":
     return requested
   if device.type == "cuda" and dtype in ("bf16", "bfloat16", "fp16"):
+    if spec is not None:
+      from ..engine import hip_executor  # pylint: disable=import-outside-toplevel
+      if not hip_executor.supports(spec):
+        # e.g. the trivial model (Flatten -> Dense(1) -> Dense): no convolution to plan around
+        logging.warning("model %s has ops without a native kernel: running it with PyTorch ops",
+                        spec.name)
+        return "torch"
     return "hip"      # a missing extension is an error on a GPU machine, not a silent fallback
   return "torch"
 
@@ -71,7 +79,7 @@ class Model:
     self.device = torch.device(device)
     self.data_format = data_format
     self.store = ParamStore(spec, self.device, seed)
-    self.executor_kind = _pick_executor_kind(executor, self.device, self.dtype)
+    self.executor_kind = _pick_executor_kind(executor, self.device, self.dtype, spec)
     self._executors: Dict[int, object] = {}
     self.optimizer: Optional[Optimizer] = None
     self.loss: Optional[str] = None

@@ -159,3 +159,21 @@ def test_native_engine_learns_a_separable_task_like_the_reference_executor():
     results[kind] = (l.item(), correct / n)
   assert results["torch"][1] > 0.95, results
   assert results["hip"][1] > 0.95, results
+
+
+def test_model_without_native_plan_falls_back_to_pytorch_ops_on_the_gpu():
+  """`--use_trivial_model --dtype fp16` on a GPU (`resnet_imagenet_main.py:189-191`): Flatten ->
+  Dense(1) -> Dense has nothing for the native planner, so `executor="auto"` runs it with
+  PyTorch ops, while an explicit `executor="hip"` still refuses."""
+  from distributed_tensorflow_amd.train.model import Model
+  dev = torch.device("cuda")
+  spec = models.trivial_model(1001)
+  m = Model(spec, dtype="bf16", device=dev)
+  assert m.executor_kind == "torch"
+  m.compile(SGD(0.01, momentum=0.9), "sparse_categorical_crossentropy", ["sparse_categorical_accuracy"])
+  x = torch.randn(4, 224, 224, 3, device=dev)
+  y = torch.randint(0, 1001, (4, 1), device=dev).float()
+  loss, _ = m.train_on_batch(x, y)
+  assert torch.isfinite(loss).item()
+  with pytest.raises(ValueError):
+    Model(spec, dtype="bf16", device=dev, executor="hip")._executor(4)
