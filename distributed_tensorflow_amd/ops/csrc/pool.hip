@@ -11,84 +11,85 @@
 
 namespace {
 
+// Both max-pool kernels walk the tensor one image row per block iteration: the (n, row) split is
+// one 32-bit division per row instead of three 64-bit divisions per 16-byte access.
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(
     const bf16_t* __restrict__ x, bf16_t* __restrict__ out, uint8_t* __restrict__ idx, int N,
     int H, int W, int C, int OH, int OW, int k, int stride, int pt, int pl) {
-  const int cpr = C >> 3;
-  const size_t total = (size_t)N * OH * OW * cpr;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const int chunk = (int)(i % cpr);
-    size_t pix = i / cpr;
-    const int ow = (int)(pix % OW); pix /= OW;
-    const int oh = (int)(pix % OH);
-    const int n = (int)(pix / OH);
-    float best[8];
-    int bi[8];
+  const uint32_t cpr = (uint32_t)C >> 3;
+  const uint32_t per_row = (uint32_t)OW * cpr;
+  for (uint32_t row = blockIdx.x; row < (uint32_t)(N * OH); row += gridDim.x) {
+    const uint32_t n = row / (uint32_t)OH, oh = row - n * (uint32_t)OH;
+    for (uint32_t j = threadIdx.x; j < per_row; j += blockDim.x) {
+      const uint32_t ow = j / cpr, chunk = j - ow * cpr;
+      float best[8];
+      int bi[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { best[c] = -INFINITY; bi[c] = 0; }
-    for (int kh = 0; kh < k; ++kh) {
-      const int hi = oh * stride - pt + kh;
-      if ((unsigned)hi >= (unsigned)H) continue;
-      for (int kw = 0; kw < k; ++kw) {
-        const int wi = ow * stride - pl + kw;
-        if ((unsigned)wi >= (unsigned)W) continue;
-        float f[8];
-        unpack8(*reinterpret_cast<const u32x4*>(x + ((size_t)(n * H + hi) * W + wi) * C + chunk * 8), f);
-        const int tap = kh * k + kw;
+      for (int c = 0; c < 8; ++c) { best[c] = -INFINITY; bi[c] = 0; }
+      for (int kh = 0; kh < k; ++kh) {
+        const int hi = (int)oh * stride - pt + kh;
+        if ((unsigned)hi >= (unsigned)H) continue;
+        for (int kw = 0; kw < k; ++kw) {
+          const int wi = (int)ow * stride - pl + kw;
+          if ((unsigned)wi >= (unsigned)W) continue;
+          float f[8];
+          unpack8(*reinterpret_cast<const u32x4*>(
+                      x + ((size_t)(n * H + hi) * W + wi) * C + chunk * 8), f);
+          const int tap = kh * k + kw;
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-          if (f[c] > best[c]) { best[c] = f[c]; bi[c] = tap; }
+          for (int c = 0; c < 8; ++c)
+            if (f[c] > best[c]) { best[c] = f[c]; bi[c] = tap; }
+        }
       }
+      const size_t o = ((size_t)row * OW + ow) * C + chunk * 8;
+      *reinterpret_cast<u32x4*>(out + o) = pack8(best);
+      u32x2 pk;
+      pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+      pk.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+      *reinterpret_cast<u32x2*>(idx + o) = pk;
     }
-    const size_t o = ((size_t)(n * OH + oh) * OW + ow) * C + chunk * 8;
-    *reinterpret_cast<u32x4*>(out + o) = pack8(best);
-    u32x2 pk;
-    pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
-    pk.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
-    *reinterpret_cast<u32x2*>(idx + o) = pk;
   }
 }
 
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(
     const bf16_t* __restrict__ dy, const uint8_t* __restrict__ idx, bf16_t* __restrict__ dx, int N,
     int H, int W, int C, int OH, int OW, int k, int stride, int pt, int pl) {
-  const int cpr = C >> 3;
-  const size_t total = (size_t)N * H * W * cpr;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const int chunk = (int)(i % cpr);
-    size_t pix = i / cpr;
-    const int w = (int)(pix % W); pix /= W;
-    const int h = (int)(pix % H);
-    const int n = (int)(pix / H);
-    float g[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) g[c] = 0.f;
-    // windows oh with 0 <= h + pt - oh*stride < k
+  const uint32_t cpr = (uint32_t)C >> 3;
+  const uint32_t per_row = (uint32_t)W * cpr;
+  for (uint32_t row = blockIdx.x; row < (uint32_t)(N * H); row += gridDim.x) {
+    const uint32_t n = row / (uint32_t)H;
+    const int h = (int)(row - n * (uint32_t)H);
+    // windows oh with 0 <= h + pt - oh*stride < k  (block-uniform)
     int oh_lo = (h + pt - k + 1 + stride - 1);
     oh_lo = oh_lo > 0 ? oh_lo / stride : 0;
     int oh_hi = (h + pt) / stride; if (oh_hi > OH - 1) oh_hi = OH - 1;
-    int ow_lo = (w + pl - k + 1 + stride - 1);
-    ow_lo = ow_lo > 0 ? ow_lo / stride : 0;
-    int ow_hi = (w + pl) / stride; if (ow_hi > OW - 1) ow_hi = OW - 1;
-    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
-      const int kh = h + pt - oh * stride;
-      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-        const int kw = w + pl - ow * stride;
-        const unsigned tap = (unsigned)(kh * k + kw);
-        const size_t o = ((size_t)(n * OH + oh) * OW + ow) * C + chunk * 8;
-        const u32x2 pk = *reinterpret_cast<const u32x2*>(idx + o);
-        float d[8];
-        unpack8(*reinterpret_cast<const u32x4*>(dy + o), d);
+    for (uint32_t j = threadIdx.x; j < per_row; j += blockDim.x) {
+      const uint32_t wu = j / cpr, chunk = j - wu * cpr;
+      const int w = (int)wu;
+      float g[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const unsigned t = ((c < 4 ? pk.x : pk.y) >> (8 * (c & 3))) & 0xffu;
-          if (t == tap) g[c] += d[c];
+      for (int c = 0; c < 8; ++c) g[c] = 0.f;
+      int ow_lo = (w + pl - k + 1 + stride - 1);
+      ow_lo = ow_lo > 0 ? ow_lo / stride : 0;
+      int ow_hi = (w + pl) / stride; if (ow_hi > OW - 1) ow_hi = OW - 1;
+      for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+        const int kh = h + pt - oh * stride;
+        for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+          const int kw = w + pl - ow * stride;
+          const unsigned tap = (unsigned)(kh * k + kw);
+          const size_t o = ((size_t)(n * OH + oh) * OW + ow) * C + chunk * 8;
+          const u32x2 pk = *reinterpret_cast<const u32x2*>(idx + o);
+          float d[8];
+          unpack8(*reinterpret_cast<const u32x4*>(dy + o), d);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const unsigned t = ((c < 4 ? pk.x : pk.y) >> (8 * (c & 3))) & 0xffu;
+            if (t == tap) g[c] += d[c];
+          }
         }
       }
+      *reinterpret_cast<u32x4*>(dx + ((size_t)row * W + w) * C + chunk * 8) = pack8(g);
     }
-    *reinterpret_cast<u32x4*>(dx + ((size_t)(n * H + h) * W + w) * C + chunk * 8) = pack8(g);
   }
 }
 
@@ -144,14 +145,18 @@ inline int grid_for(size_t total) {
 void launch_maxpool_fwd(const bf16_t* x, bf16_t* out, uint8_t* idx, int N, int H, int W, int C,
                         int OH, int OW, int k, int stride, int pt, int pl, hipStream_t s) {
   if (C % 8 || k * k > 255) throw std::invalid_argument("maxpool: C %% 8 != 0 or window too large");
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((size_t)N * OH * OW * (C / 8))), dim3(256),
+  if ((int64_t)N * H * W * (C / 8) >= (1ll << 31)) throw std::invalid_argument("maxpool: tensor too large");
+  const int rows = N * OH;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(rows < 8192 ? rows : 8192), dim3(256),
                      0, s, x, out, idx, N, H, W, C, OH, OW, k, stride, pt, pl);
 }
 
 void launch_maxpool_bwd(const bf16_t* dy, const uint8_t* idx, bf16_t* dx, int N, int H, int W,
                         int C, int OH, int OW, int k, int stride, int pt, int pl, hipStream_t s) {
   if (C % 8) throw std::invalid_argument("maxpool: C %% 8 != 0");
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((size_t)N * H * W * (C / 8))), dim3(256), 0,
+  if ((int64_t)N * H * W * (C / 8) >= (1ll << 31)) throw std::invalid_argument("maxpool: tensor too large");
+  const int rows = N * H;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(rows < 8192 ? rows : 8192), dim3(256), 0,
                      s, dy, idx, dx, N, H, W, C, OH, OW, k, stride, pt, pl);
 }
 
