@@ -22,7 +22,8 @@ from . import conv_plan
 __all__ = ["signature", "lookup", "apply", "tune", "save", "enabled", "CACHE_PATH"]
 
 CACHE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
-_POINTERS = ("in", "wgt", "out", "addend", "addend_mask", "bias", "stats", "x", "dy", "dw")
+_POINTERS = ("in", "wgt", "out", "addend", "addend_mask", "bias", "stats", "stats_y",
+             "stats_mask", "x", "dy", "dw")
 _IGNORED = _POINTERS + ("cfg", "splits", "stats_replicas")
 _cache: Optional[Dict[str, Dict[str, int]]] = None
 _dirty = False
@@ -52,6 +53,8 @@ def signature(kind: str, desc: Dict) -> str:
     parts.append("%s=%s" % (k, desc[k]))
   for k in ("addend", "addend_mask", "bias", "stats"):
     if desc.get(k) is not None:
+      if k == "stats" and desc.get("stats_y") is not None:
+        continue      # backward statistics ride on a data gradient: tuned as the plain launch
       parts.append("+" + k)
   return "|".join(parts)
 

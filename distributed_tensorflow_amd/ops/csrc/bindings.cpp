@@ -57,6 +57,8 @@ ConvParams conv_from_dict(const py::dict& d) {
   p.bias = ptr<const float>(d, "bias", false);
   p.stats = ptr<float>(d, "stats", false);
   p.stats_replicas = get_or<int>(d, "stats_replicas", 0);
+  p.stats_y = ptr<const bf16_t>(d, "stats_y", false);
+  p.stats_mask = ptr<const uint8_t>(d, "stats_mask", false);
   p.N = get<int>(d, "N"); p.H = get<int>(d, "H"); p.W = get<int>(d, "W");
   p.Cpix = get<int>(d, "Cpix");
   p.OH = get<int>(d, "OH"); p.OW = get<int>(d, "OW");
@@ -164,8 +166,11 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     auto dy = ptr<bf16_t>(d, "dy"); auto dres = ptr<bf16_t>(d, "dres", false);
     auto ws = ptr<float>(d, "ws");
     const int P = get<int>(d, "P"), C = get<int>(d, "C");
+    // > 0: `ws` already holds that many replica rows of [sum g | sum g*y] left by the data-
+    // gradient launches that produced dz; the reduction sweep is skipped
+    const int pre = get_or<int>(d, "pre_replicas", 0);
     return [=](hipStream_t s) {
-      launch_bn_bwd(dz, y, z, mask, mean, inv, gamma, dgamma, dbeta, dy, dres, ws, P, C, s);
+      launch_bn_bwd(dz, y, z, mask, mean, inv, gamma, dgamma, dbeta, dy, dres, ws, P, C, pre, s);
     };
   }
   if (kind == "mask_apply") {

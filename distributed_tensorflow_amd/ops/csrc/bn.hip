@@ -286,6 +286,8 @@ struct BnBwdArgs {
   bf16_t* dy; bf16_t* dres;
   float* ws; int G;
   int P, C;
+  int raw;                  // 1: `ws` rows hold [sum g | sum g*y] (from the data-gradient
+                            // epilogues) instead of [dgamma | dbeta]
 };
 
 __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
@@ -347,9 +349,14 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
 __global__ __launch_bounds__(FIN_TPB) void bn_bwd_finalize_kernel(const BnBwdArgs a) {
   __shared__ float red[FIN_TPB];
   const int ch = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
-  const float dg = column_sum(a.ws, a.G, 2 * a.C, ch, rl, red);
-  const float db = column_sum(a.ws, a.G, 2 * a.C, a.C + ch, rl, red);
+  float dg = column_sum(a.ws, a.G, 2 * a.C, ch, rl, red);
+  float db = column_sum(a.ws, a.G, 2 * a.C, a.C + ch, rl, red);
   if (rl == 0 && ch < a.C) {
+    if (a.raw) {           // dg = sum g, db = sum g*y  ->  dbeta, dgamma = sum g * xhat
+      const float sg = dg, sgy = db;
+      db = sg;
+      dg = (sgy - a.mean[ch] * sg) * a.invstd[ch];
+    }
     a.dgamma[ch] = dg;     // plain stores into the flat gradient buffer
     a.dbeta[ch] = db;
   }
@@ -502,11 +509,14 @@ void launch_bn_infer(const bf16_t* y, const bf16_t* res, bf16_t* z, const float*
 void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const uint8_t* mask,
                    const float* mean, const float* invstd, const float* gamma, float* dgamma,
                    float* dbeta, bf16_t* dy, bf16_t* dres, float* ws, int P, int C,
-                   hipStream_t s) {
+                   int pre_replicas, hipStream_t s) {
   check_channels(C, P);
-  const int G = reduce_grid(P, C);
-  BnBwdArgs a{dz, y, z, mask, mean, invstd, gamma, dgamma, dbeta, dy, dres, ws, G, P, C};
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(G), dim3(TPB), 0, s, a);
+  if (pre_replicas < 0) throw std::invalid_argument("bn_bwd: negative replica count");
+  const int G = pre_replicas > 0 ? pre_replicas : reduce_grid(P, C);
+  BnBwdArgs a{dz, y, z, mask, mean, invstd, gamma, dgamma, dbeta, dy, dres, ws, G, P, C,
+              pre_replicas > 0 ? 1 : 0};
+  if (pre_replicas == 0)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(G), dim3(TPB), 0, s, a);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, a);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
 }

@@ -84,7 +84,10 @@ constexpr int GENERIC = 0, POINTWISE_MODE = 1, TAPLOOP = 2;
 
 // Second launch-bound argument = waves per SIMD the register allocation must allow: 4 blocks
 // of 4 waves per CU (64 accumulator registers + ~60 others fit the 128-register budget).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
+// BSTATS selects the backward flavour of the fused statistics (sum g, sum g*y; see ConvParams)
+// at compile time: the extra loads and registers of that epilogue stay out of the forward
+// instantiations.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool BSTATS = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 4)
 void conv_igemm_kernel(const ConvParams p) {
   constexpr bool POINTWISE = MODE == POINTWISE_MODE;
@@ -367,13 +370,29 @@ void conv_igemm_kernel(const ConvParams p) {
           *reinterpret_cast<u32x4*>(optr + h * 8) = o;
           if (p.stats) {
             const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+            if constexpr (BSTATS) {                  // sum g, sum g * y  (g = masked output)
+              const u32x4 yq = *reinterpret_cast<const u32x4*>(p.stats_y + obase + co0 + h * 8);
+              const uint32_t yw[4] = {yq.x, yq.y, yq.z, yq.w};
+              const uint32_t sb = p.stats_mask
+                  ? p.stats_mask[opix * (p.ldc >> 3) + (co0 >> 3) + h] : 0xffu;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
-              st[h * 8 + 2 * j] += lo;
-              st[h * 8 + 2 * j + 1] += hi;
-              st[CPL + h * 8 + 2 * j] += lo * lo;
-              st[CPL + h * 8 + 2 * j + 1] += hi * hi;
+              for (int j = 0; j < 4; ++j) {
+                const float lo = (sb >> (2 * j)) & 1u ? __uint_as_float(w[j] << 16) : 0.f;
+                const float hi = (sb >> (2 * j + 1)) & 1u ? __uint_as_float(w[j] & 0xffff0000u) : 0.f;
+                st[h * 8 + 2 * j] += lo;
+                st[h * 8 + 2 * j + 1] += hi;
+                st[CPL + h * 8 + 2 * j] += lo * __uint_as_float(yw[j] << 16);
+                st[CPL + h * 8 + 2 * j + 1] += hi * __uint_as_float(yw[j] & 0xffff0000u);
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+                st[h * 8 + 2 * j] += lo;
+                st[h * 8 + 2 * j + 1] += hi;
+                st[CPL + h * 8 + 2 * j] += lo * lo;
+                st[CPL + h * 8 + 2 * j + 1] += hi * hi;
+              }
             }
           }
         } else {
@@ -409,13 +428,29 @@ void conv_igemm_kernel(const ConvParams p) {
         *reinterpret_cast<u32x2*>(optr) = o;
         if (p.stats) {
           const uint32_t w[2] = {o.x, o.y};
+          if constexpr (BSTATS) {
+            const u32x2 yq = *reinterpret_cast<const u32x2*>(p.stats_y + obase + co0);
+            const uint32_t yw[2] = {yq.x, yq.y};
+            const uint32_t sb = p.stats_mask
+                ? (uint32_t)p.stats_mask[opix * (p.ldc >> 3) + (co0 >> 3)] >> (co0 & 4) : 0xffu;
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
-            st[2 * j] += lo;
-            st[2 * j + 1] += hi;
-            st[CPL + 2 * j] += lo * lo;
-            st[CPL + 2 * j + 1] += hi * hi;
+            for (int j = 0; j < 2; ++j) {
+              const float lo = (sb >> (2 * j)) & 1u ? __uint_as_float(w[j] << 16) : 0.f;
+              const float hi = (sb >> (2 * j + 1)) & 1u ? __uint_as_float(w[j] & 0xffff0000u) : 0.f;
+              st[2 * j] += lo;
+              st[2 * j + 1] += hi;
+              st[CPL + 2 * j] += lo * __uint_as_float(yw[j] << 16);
+              st[CPL + 2 * j + 1] += hi * __uint_as_float(yw[j] & 0xffff0000u);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+              st[2 * j] += lo;
+              st[2 * j + 1] += hi;
+              st[CPL + 2 * j] += lo * lo;
+              st[CPL + 2 * j + 1] += hi * hi;
+            }
           }
         }
       } else {
@@ -451,8 +486,8 @@ void conv_igemm_kernel(const ConvParams p) {
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-void launch_cfg(const ConvParams& p, hipStream_t stream) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BSTATS>
+void launch_cfg_stats(const ConvParams& p, hipStream_t stream) {
   const int tilesN = (p.Cout + BN - 1) / BN;
   const int tilesM = (p.M + BM - 1) / BM;
   const int grid = ((tilesM + 7) / 8) * 8 * tilesN;
@@ -461,14 +496,20 @@ void launch_cfg(const ConvParams& p, hipStream_t stream) {
                          p.OH == p.H && p.OW == p.W && p.OHfull == p.OH && p.OWfull == p.OW &&
                          p.Ctap <= p.Cpix;
   if (pointwise)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, POINTWISE_MODE>), dim3(grid),
-                       dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, POINTWISE_MODE, BSTATS>),
+                       dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
   else if (p.Ctap % BK == 0)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, TAPLOOP>), dim3(grid),
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, TAPLOOP, BSTATS>), dim3(grid),
                        dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, GENERIC>), dim3(grid),
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, GENERIC, BSTATS>), dim3(grid),
                        dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+void launch_cfg(const ConvParams& p, hipStream_t stream) {
+  if (p.stats_y) launch_cfg_stats<BM, BN, WAVES_M, WAVES_N, true>(p, stream);
+  else launch_cfg_stats<BM, BN, WAVES_M, WAVES_N, false>(p, stream);
 }
 
 }  // namespace
@@ -493,9 +534,12 @@ void validate_conv_params(const ConvParams& p) {
   }
   if (p.stats) {
     if (p.stats_replicas <= 0) fail("stats needs a positive replica count");
-    if (p.bias || p.addend) fail("fused statistics need a plain convolution (no bias / addend)");
+    if (p.bias) fail("fused statistics need a bias-free convolution");
+    if (p.addend && !p.stats_y) fail("forward statistics need a plain convolution (no addend)");
     if (p.Cout % 8 || p.ldc % 8) fail("fused statistics need Cout and ldc to be multiples of 8");
   }
+  if ((p.stats_y || p.stats_mask) && !p.stats) fail("stats_y / stats_mask without a stats buffer");
+  if (p.stats_mask && !p.stats_y) fail("stats_mask belongs to the backward statistics (stats_y)");
   if ((p.OH - 1) * p.OSH + p.OOH >= p.OHfull || (p.OW - 1) * p.OSW + p.OOW >= p.OWfull)
     fail("output index overrun");
   // every in-bounds pixel read must stay inside the input tensor: pixel*Cpix + Ctap <= total

@@ -18,6 +18,13 @@ struct ConvParams {
   // stats[replicas][2][Cout]; the buffer is zeroed by the caller
   float* stats = nullptr;
   int stats_replicas = 0;
+  // Backward flavour of the fused statistics (data-gradient launches): with `stats_y` set the
+  // two accumulated quantities are  sum g  and  sum g * y,  where g is the (bf16 rounded)
+  // output gated by the 1-bit `stats_mask` (null: ungated) and y is `stats_y` at the same
+  // position - the reductions of the BatchNorm backward pass whose incoming gradient this
+  // launch produces.  Bias-free; an addend is allowed (it is part of the gradient).
+  const bf16_t* stats_y = nullptr;
+  const uint8_t* stats_mask = nullptr;
   int N = 0, H = 0, W = 0, Cpix = 0;
   int OH = 0, OW = 0, M = 0;       // logical output grid; M = N*OH*OW
   int OHfull = 0, OWfull = 0, ldc = 0;

@@ -17,7 +17,7 @@ void launch_bn_infer(const bf16_t* y, const bf16_t* res, bf16_t* z, const float*
 void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const uint8_t* mask,
                    const float* mean, const float* invstd, const float* gamma, float* dgamma,
                    float* dbeta, bf16_t* dy, bf16_t* dres, float* ws, int P, int C,
-                   hipStream_t s);
+                   int pre_replicas, hipStream_t s);
 
 // out[i] = bit (i % 8) of mask[i / 8] ? x[i] : 0, n a multiple of 8 (materialises a masked
 // gradient when its consumer cannot apply the mask itself).

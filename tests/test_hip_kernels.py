@@ -147,6 +147,71 @@ def test_conv_fused_bn_statistics(case):
     assert torch.allclose(z.float(), ref, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, K, Cout, stride, cfg, with_mask, with_addend
+    (3, 20, 20, 64, 3, 72, 1, 0, True, False), (2, 14, 14, 256, 1, 128, 1, 6, True, True),
+    (3, 19, 19, 128, 3, 64, 2, 5, True, True), (2, 16, 16, 64, 1, 96, 2, 1, False, False),
+    (3, 17, 17, 16, 3, 32, 1, 3, True, False), (2, 12, 12, 512, 1, 64, 1, 4, True, True)])
+def test_dgrad_fused_bn_backward_statistics(case):
+  """Data gradient with the backward flavour of the fused statistics: per-channel sum g and
+  sum g*y (g = stored bf16 gradient gated by a 1-bit mask) over every parity launch, and the
+  BatchNorm backward that consumes the replicas instead of running its reduction sweep."""
+  native = _native()
+  N, H, W, Cin, K, Cout, stride, cfg, with_mask, with_addend = case
+  dev = torch.device("cuda")
+  gen = torch.Generator(device="cpu").manual_seed(sum(case[:8]))
+  pad = same_padding(H, K, stride) + same_padding(W, K, stride)
+  g = ConvGeom(N, H, W, Cin, K, K, Cout, stride, pad)
+  w = (torch.randn(K, K, Cin, Cout, generator=gen) * (1.0 / math.sqrt(K * K * Cout))).to(dev)
+  wd = _pack(native, g, w, "dgrad")
+  dyc = _bf(torch.randn(N, g.OH, g.OW, Cout, generator=gen)).to(dev)
+  y = _bf(torch.randn(N, H, W, Cin, generator=gen) * 1.5 + 0.7).to(dev)       # BatchNorm input
+  bits = torch.rand(N * H * W, Cin, generator=gen) > 0.4
+  mask = (bits.view(-1, Cin // 8, 8).to(torch.int32) << torch.arange(8)).sum(-1).to(torch.uint8)
+  mask = torch.cat([mask.flatten(), torch.zeros(4, dtype=torch.uint8)]).to(dev)
+  addend = _bf(torch.randn(N, H, W, Cin, generator=gen)).to(dev) if with_addend else None
+  R = 32
+  stats = torch.zeros(R, 2, Cin, device=dev)
+  dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=dev)
+  for d in g.dgrad(dyc.data_ptr(), wd.data_ptr(), dx.data_ptr(), cfg=cfg,
+                   addend=addend.data_ptr() if with_addend else None):
+    d.update(stats=stats.data_ptr(), stats_replicas=R, stats_y=y.data_ptr(),
+             stats_mask=mask.data_ptr() if with_mask else None)
+    native.run_op("conv", d)
+  torch.cuda.synchronize()
+  gq = dx.float().reshape(-1, Cin)
+  assert torch.isfinite(gq).all()
+  if with_mask:
+    gq = gq * bits.to(dev)
+  yq = y.float().reshape(-1, Cin)
+  tot = stats.sum(0)
+  scale = gq.abs().sum(0).max().item()
+  assert torch.allclose(tot[0], gq.sum(0), rtol=1e-3, atol=1e-4 * scale + 1e-2)
+  assert torch.allclose(tot[1], (gq * yq).sum(0), rtol=1e-3, atol=1e-4 * scale + 1e-2)
+  if Cin & (Cin - 1) == 0:
+    # BatchNorm backward from the replicas == BatchNorm backward with its own reduction
+    P = gq.shape[0]
+    mean, var = yq.mean(0), yq.var(0, unbiased=False)
+    saved = torch.cat([mean, torch.rsqrt(var + 1e-5)]).contiguous()
+    gamma = (torch.rand(Cin, generator=gen) + 0.5).to(dev)
+    ws = torch.zeros(native.ext().bn_workspace_floats(), device=dev)
+    outs = []
+    for pre in (0, R):
+      dgamma, dbeta = torch.zeros(Cin, device=dev), torch.zeros(Cin, device=dev)
+      dyb = torch.empty(P, Cin, dtype=torch.bfloat16, device=dev)
+      native.run_op("bn_bwd", dict(
+          dz=dx.data_ptr(), y=y.data_ptr(), z=None, mask=mask.data_ptr() if with_mask else None,
+          mean=saved.data_ptr(), invstd=saved.data_ptr() + 4 * Cin, gamma=gamma.data_ptr(),
+          dgamma=dgamma.data_ptr(), dbeta=dbeta.data_ptr(), dy=dyb.data_ptr(), dres=None,
+          ws=stats.data_ptr() if pre else ws.data_ptr(), pre_replicas=pre, P=P, C=Cin))
+      torch.cuda.synchronize()
+      outs.append((dgamma, dbeta, dyb.float()))
+    tol = 2e-3 * max(outs[0][0].abs().max().item(), outs[0][1].abs().max().item()) + 1e-2
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=2e-3, atol=tol)
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=2e-3, atol=tol)
+    assert torch.allclose(outs[0][2], outs[1][2], rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("cfg", [0, 1, 4, 5, 6])
 @pytest.mark.parametrize("shape", [(3, 19, 19, 64, 3, 136, 2), (2, 15, 15, 96, 1, 264, 1),
                                    (2, 14, 14, 32, 3, 128, 1)])
