@@ -110,6 +110,20 @@ def test_imagenet_resnet50_native_end_to_end(tmp_path, small_validation):
   assert stats["loss"] > 0 and "avg_exp_per_second" in stats
 
 
+@pytest.mark.gpu
+def test_profile_steps_traces_native_kernels(tmp_path, small_validation):
+  """`--profile_steps a,b` (`common.py:192-197`) on the native engine: the trace written to
+  `model_dir` contains the hand-written kernels."""
+  resnet_cifar_main.define_cifar_flags()
+  integration.run_synthetic(
+      main=resnet_cifar_main.run, tmp_root=str(tmp_path),
+      extra_flags=["-batch_size", "16", "-train_steps", "12", "-num_gpus", "1", "-dtype", "bf16",
+                   "-distribution_strategy", "off", "-skip_eval", "-profile_steps", "10,11",
+                   "-model_dir", str(tmp_path / "prof")], max_train=None)
+  trace = (tmp_path / "prof" / "profile_steps_10_11.trace.json").read_text()
+  assert "conv_igemm_kernel" in trace and "bn_apply_kernel" in trace
+
+
 def _free_ports(n):
   import socket
   socks = [socket.socket() for _ in range(n)]
