@@ -116,7 +116,8 @@ def define_keras_flags(dynamic_loss_scale=True):
   f.DEFINE_integer("seed", 0, "Seed of the variable initialisers.")
   f.DEFINE_string("resume", None, "Keras-layout HDF5 checkpoint to restore before training.")
   f.DEFINE_integer("fusion_threshold_mb", None,
-                   "Gradient fusion bucket size in MB (overrides --num_packs).")
+                   "Gradient fusion bucket size in MB (overrides --num_packs; with neither "
+                   "flag given the buckets are 25 MB).")
   f.DEFINE_boolean("use_hip_graph", True, "Replay the training step as a captured hipGraph "
                    "when the strategy allows it.")
   f.DEFINE_boolean("deterministic", False, "Fixed-order BatchNorm statistics, and a check "

@@ -168,6 +168,8 @@ class ParamStore:
     return 0.5 * torch.dot(self.l2_vector(), self.params * self.params)
 
   # -- buckets -----------------------------------------------------------------
+  TAIL_BUCKET_BYTES = 2 << 20
+
   def make_buckets(self, num_packs: int = 1, bucket_bytes: Optional[int] = None) -> List[Bucket]:
     """Splits the gradient buffer into contiguous fusion buckets.
 
@@ -175,6 +177,11 @@ class ParamStore:
     the last layers first, so bucket 0 is the tail of the buffer.  `num_packs`
     equal-sized packs (reference flag `--num_packs`), or a byte budget per bucket
     (Horovod's fusion threshold); `num_packs=0` gives one bucket per variable.
+
+    With several buckets on a large model the last one is additionally cut so that what
+    completes at the very end of the backward pass (the first layers of the network) is a small
+    bucket of its own: its collective is the only one that cannot overlap any compute, so it
+    should be latency-sized (`TAIL_BUCKET_BYTES`), not a full pack.
     """
     tv = self.trainable
     if not tv:
@@ -186,12 +193,21 @@ class ParamStore:
       target = -(-total // num_packs)
     else:
       target = 1
+    tail = self.TAIL_BUCKET_BYTES // 4
+    split_tail = (bucket_bytes or (num_packs and num_packs > 1)) and total > 8 * tail \
+        and target > 2 * tail
     buckets: List[Bucket] = []
     cur: List[VarEntry] = []
     cur_n = 0
+    left = total
     for e in reversed(tv):
+      if split_tail and cur and left <= tail:
+        buckets.append(self._mk_bucket(len(buckets), cur))   # what follows is the tail bucket
+        cur, cur_n = [], 0
+        split_tail = False
       cur.append(e)
       cur_n += e.padded
+      left -= e.padded
       if cur_n >= target:
         buckets.append(self._mk_bucket(len(buckets), cur))
         cur, cur_n = [], 0

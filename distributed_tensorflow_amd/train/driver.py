@@ -102,6 +102,12 @@ def _make_strategy(flags_obj, use_horovod: bool):
   bucket_bytes = None
   if flags_obj.fusion_threshold_mb:
     bucket_bytes = int(flags_obj.fusion_threshold_mb) * 1024 * 1024
+  elif flags_obj.num_packs == 1:
+    # The reference's default (one pack) would leave a single collective that can only start
+    # when the whole backward pass is done.  Unless packs are asked for explicitly, gradients
+    # are reduced in 25 MB buckets that overlap the backward pass (small models still end up
+    # with one bucket).
+    bucket_bytes = 25 * 1024 * 1024
   strategy = strategy_lib.get_distribution_strategy(
       distribution_strategy=flags_obj.distribution_strategy,
       num_gpus=flags_obj.num_gpus, num_workers=num_workers,

@@ -86,6 +86,15 @@ def test_param_store_layout_and_buckets():
       assert len(bs) <= packs + 1
   assert len(st.make_buckets(0)) == len(st.trainable)
   assert len(st.make_buckets(bucket_bytes=1 << 20)) >= 3
+  # large model, several packs: the bucket that completes last (first layers) is latency-sized
+  big = ParamStore(models.resnet50(), "cpu", seed=0)
+  bs = big.make_buckets(4)
+  covered = sorted((b.start, b.end) for b in bs)
+  assert covered[0][0] == 0 and covered[-1][1] == big.num_elements
+  assert all(a1 == b0 for (_, a1), (b0, _) in zip(covered, covered[1:]))
+  assert len(bs) == 5 and "conv1/kernel" in bs[-1].var_names
+  assert (bs[-1].end - bs[-1].start) * 4 <= ParamStore.TAIL_BUCKET_BYTES
+  assert len(big.make_buckets(1)) == 1                 # --num_packs 1 stays one collective
   # deterministic init
   st2 = ParamStore(m, "cpu", seed=1)
   st.initialize(1)
