@@ -328,3 +328,45 @@ def test_one_rank_collective_rehearsal_issues_real_collectives(tmp_path):
   assert out["rehearsed"]["ncoll"] == 10 * 3 and out["plain"]["ncoll"] == 0
   assert out["rehearsed"]["losses"] == pytest.approx(out["plain"]["losses"], rel=1e-5)
   assert out["rehearsed"]["psum"] == pytest.approx(out["plain"]["psum"], rel=1e-7)
+
+
+def test_torchrun_launch_with_agent_store(tmp_path):
+  """`python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P`
+  (how the multi-GPU benchmark is started): ranks come from RANK / LOCAL_RANK / WORLD_SIZE, the
+  rendezvous reuses the launcher's store on MASTER_PORT, and the strategy reduces gradients."""
+  script = tmp_path / "w.py"
+  script.write_text("import sys, os, json\nsys.path.insert(0, %r)\nimport torch\n" % ROOT + textwrap.dedent("""
+    torch.set_num_threads(1)
+    from distributed_tensorflow_amd import models
+    from distributed_tensorflow_amd.parallel import strategy as S, comm
+    from distributed_tensorflow_amd.train.model import Model
+    from distributed_tensorflow_amd.train.optimizers import SGD
+    strat = S.MirroredStrategy(use_gpu=False, num_packs=2)
+    assert strat.num_replicas_in_sync == 2 and strat.rank == int(os.environ["RANK"])
+    m = Model(models.resnet20(), strategy=strat, dtype="fp32", seed=strat.rank)
+    m.compile(SGD(0.05, momentum=0.9), "sparse_categorical_crossentropy")
+    g = torch.Generator().manual_seed(strat.rank)
+    x = torch.randn(4, 32, 32, 3, generator=g) * 50 + 100
+    y = torch.randint(0, 10, (4, 1), generator=g).float()
+    for _ in range(2):
+      m.train_on_batch(x, y)
+    t = torch.tensor([m.store.params.double().sum().item()], dtype=torch.float64)
+    lo, hi = t.clone(), t.clone()
+    torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+    torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+    assert lo.item() == hi.item(), (lo, hi)
+    strat.barrier()
+    if strat.rank == 0:
+      open(os.path.join(%r, "ok"), "w").write("ok")
+    comm.shutdown()
+  """ % str(tmp_path)))
+  import socket
+  s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+  env = dict(os.environ, OMP_NUM_THREADS="1")
+  for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TF_CONFIG", "MASTER_ADDR", "MASTER_PORT"):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                      "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                      str(port), str(script)], env=env, capture_output=True, text=True, timeout=300)
+  assert r.returncode == 0, r.stderr[-3000:]
+  assert (tmp_path / "ok").exists()
