@@ -100,6 +100,7 @@ class HipExecutor:
     self.fused_bn_stats = fused_bn_stats
     self.overlap_wgrad = os.environ.get("DTF_WGRAD_STREAM", "1") != "0"
     self._keep: List[torch.Tensor] = []      # owns every planned buffer
+    self._soft_joins = False
     self._graph_stream: Optional[torch.cuda.Stream] = None
     self._train_graph = None
     self._pool_idx: Dict[str, torch.Tensor] = {}
@@ -399,7 +400,10 @@ class HipExecutor:
           ready.append(by_index[bi])
       if ready:
         if self.overlap_wgrad:
-          plan.add("join", {}, "join")        # the bucket's gradients are complete past here
+          # The bucket's gradients are complete once the side lane has caught up.  A soft join:
+          # a reducer that waits for the side lane on its communication stream lets the main
+          # lane run on (train_step(soft_joins=True)); otherwise the main lane waits here.
+          plan.add("soft_join", {}, "join")
         self._segments.append((seg_begin, plan.size(), ready))
         seg_begin = plan.size()
 
@@ -521,9 +525,9 @@ class HipExecutor:
         done([op.name + "/kernel"])
       for t in op.inputs:
         uses_left[t] = uses_left.get(t, 0) - 1
+    if self.overlap_wgrad:
+      plan.add("join", {}, "join")               # the step ends with the side lane collected
     if seg_begin < plan.size() or not self._segments:
-      if self.overlap_wgrad:
-        plan.add("join", {}, "join")
       self._segments.append((seg_begin, plan.size(), []))
     left = [i for i, r in remaining.items() if r]
     if left:
@@ -582,8 +586,12 @@ class HipExecutor:
       self._loss_scale = float(s)
 
   def train_step(self, images: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0,
-                 on_bucket_ready: Optional[Callable[[Bucket], None]] = None
-                 ) -> Tuple[torch.Tensor, torch.Tensor]:
+                 on_bucket_ready: Optional[Callable[[Bucket], None]] = None,
+                 soft_joins: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`soft_joins`: `on_bucket_ready` orders its work behind the side lane itself
+    (`side_stream()`), so the main lane need not wait for the weight gradients at bucket
+    boundaries (eager launch only; captured graphs keep the joins)."""
+    self._soft_joins = bool(soft_joins and on_bucket_ready is not None)
     with torch.cuda.device(self.device):
       self._ensure_packed()
       self._stage(images, labels)
@@ -604,9 +612,14 @@ class HipExecutor:
       self.bwd_plan.run(0, self.bwd_plan.size(), s)
       return
     for begin, end, ready in self._segments:
-      self.bwd_plan.run(begin, end, s)
+      self.bwd_plan.run(begin, end, s, self._soft_joins)
       for b in ready:
         on_bucket_ready(b)
+
+  def side_stream(self) -> Optional["torch.cuda.Stream"]:
+    """The plans' side lane (weight gradients), once it exists."""
+    h = native.ext().Plan.side_stream()
+    return torch.cuda.ExternalStream(h, device=self.device) if h else None
 
   def _calibrate_step(self, on_bucket_ready=None):
     """Auto mode: steps 0-3 eager (2-3 timed), step 4 captures, steps 5-7 replay (6-7 timed).

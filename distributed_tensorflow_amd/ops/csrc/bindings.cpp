@@ -371,6 +371,7 @@ class Plan {
     e.lane = lane;
     if (kind == "fork") e.type = FORK;
     else if (kind == "join") e.type = JOIN;
+    else if (kind == "soft_join") e.type = SOFT_JOIN;
     else e.launch = make_op(kind, args);
     if (e.type != OP) {
       hipEvent_t ev;
@@ -385,11 +386,16 @@ class Plan {
   int size() const { return (int)ops_.size(); }
   std::string name(int i) const { return names_.at(i); }
   int lane(int i) const { return ops_.at(i).lane; }
-  void run(int begin, int end, uintptr_t stream) {
+  // `skip_soft_joins`: the caller orders whatever consumes the side lane's results itself (see
+  // side_stream()), so "soft_join" entries do not make the main lane wait.  The range may then
+  // end with side-lane work in flight; a later hard "join" (or run without the flag) collects it.
+  void run(int begin, int end, uintptr_t stream, bool skip_soft_joins) {
     if (begin < 0 || end > (int)ops_.size() || begin > end) throw std::out_of_range("Plan.run range");
-    enqueue(begin, end, reinterpret_cast<hipStream_t>(stream));
+    enqueue(begin, end, reinterpret_cast<hipStream_t>(stream), skip_soft_joins);
     check_launch();
   }
+  // The side lane of all plans (0 before its first use).
+  static uintptr_t side_stream() { return reinterpret_cast<uintptr_t>(shared_side()); }
   // Captures ops [begin, end) on `stream` into a hipGraph; returns a handle for replay().
   // The range must end with the side lane joined (the capture cannot end otherwise).
   int capture(int begin, int end, uintptr_t stream) {
@@ -398,7 +404,7 @@ class Plan {
     Graph g;
     HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     try {
-      enqueue(begin, end, s);
+      enqueue(begin, end, s, false);
     } catch (...) {
       hipGraph_t tmp = nullptr;
       (void)hipStreamEndCapture(s, &tmp);
@@ -415,7 +421,7 @@ class Plan {
   }
 
  private:
-  enum Type { OP, FORK, JOIN };
+  enum Type { OP, FORK, JOIN, SOFT_JOIN };
   struct Entry {
     Type type = OP;
     int lane = 0;
@@ -447,14 +453,18 @@ class Plan {
     }
     return side_;
   }
-  void enqueue(int begin, int end, hipStream_t main) {
-    bool side_busy = false;          // side lane holds work the main lane has not waited for
+  void enqueue(int begin, int end, hipStream_t main, bool skip_soft_joins) {
+    // side lane holds work the main lane has not waited for (possibly from an earlier range
+    // that ended on a skipped soft join)
+    bool side_busy = side_pending_;
     for (int i = begin; i < end; ++i) {
       Entry& e = ops_[i];
       if (e.type == FORK) {
         HIP_CHECK(hipEventRecord(e.event, main));
         HIP_CHECK(hipStreamWaitEvent(side(main), e.event, 0));
-      } else if (e.type == JOIN) {
+      } else if (e.type == SOFT_JOIN && skip_soft_joins) {
+        // nothing: the consumer of the side lane's results waits on side_stream() itself
+      } else if (e.type == JOIN || e.type == SOFT_JOIN) {
         if (side_busy) {
           HIP_CHECK(hipEventRecord(e.event, side(main)));
           HIP_CHECK(hipStreamWaitEvent(main, e.event, 0));
@@ -467,13 +477,16 @@ class Plan {
         e.launch(main);
       }
     }
-    if (side_busy) throw std::logic_error("Plan: range ends with unjoined side-lane work");
+    if (side_busy && !skip_soft_joins)
+      throw std::logic_error("Plan: range ends with unjoined side-lane work");
+    side_pending_ = side_busy;
   }
 
   std::vector<Entry> ops_;
   std::vector<std::string> names_;
   std::vector<Graph> graphs_;
   std::vector<hipEvent_t> events_;
+  bool side_pending_ = false;
 };
 
 }  // namespace
@@ -504,7 +517,9 @@ PYBIND11_MODULE(_dtf_native, m) {
       .def("lane", &Plan::lane)
       .def("size", &Plan::size)
       .def("name", &Plan::name)
-      .def("run", &Plan::run, py::arg("begin"), py::arg("end"), py::arg("stream") = 0)
+      .def("run", &Plan::run, py::arg("begin"), py::arg("end"), py::arg("stream") = 0,
+           py::arg("skip_soft_joins") = false)
+      .def_static("side_stream", &Plan::side_stream)
       .def("capture", &Plan::capture)
       .def("replay", &Plan::replay);
 }

@@ -59,6 +59,7 @@ class GradientReducer:
     self._pending = []
     self._stream = None            # None: not decided yet; False: torch.distributed's own stream
     self._stream_pending = False
+    self._side = None              # the executor's side lane, when it orders its results here
     self.bytes_reduced = 0
     self.collectives_launched = 0
 
@@ -92,6 +93,19 @@ class GradientReducer:
           h = native.ext().concurrent_stream(int(cur.cuda_stream), prio)
           self._stream = torch.cuda.ExternalStream(h, device=device)
     return self._stream or None
+
+  def orders_side_lane(self, executor) -> bool:
+    """True when every bucket's collective is issued on this reducer's own stream, which then
+    also waits for the executor's side lane (weight gradients): the executor may skip the
+    main-lane joins at bucket boundaries (`HipExecutor.train_step(soft_joins=True)`)."""
+    if self.n <= 1 and not getattr(self.comm, "rehearse", False):
+      return False
+    if not hasattr(executor, "side_stream") or self.store.grads.device.type != "cuda":
+      return False
+    if self._own_stream(self.store.grads.device) is None:
+      return False
+    self._executor = executor
+    return True
 
   def _issue(self, g: torch.Tensor, async_op: bool):
     """The bucket's collective(s); returns the last work handle (None for blocking calls)."""
@@ -135,6 +149,12 @@ class GradientReducer:
       # gradients enqueued so far, the collective is issued as a blocking-API call *on that
       # stream*, and finish() makes the compute stream wait for the communication stream
       cs.wait_stream(torch.cuda.current_stream(g.device))
+      ex = getattr(self, "_executor", None)
+      if ex is not None:
+        if self._side is None:
+          self._side = ex.side_stream()          # None until the side lane has been used
+        if self._side is not None:
+          cs.wait_stream(self._side)             # weight gradients of this bucket
       with torch.cuda.stream(cs):
         self._issue(g, async_op=False)
       self._stream_pending = True

@@ -196,8 +196,13 @@ class Model:
       self.optimizer.iterations += 1
       return loss, correct
     red = self._grad_reducer()
-    loss, correct = ex.train_step(images, idx, self._loss_scale(),
-                                  red.on_bucket_ready if red is not None else None)
+    if red is not None and getattr(ex, "native", False) and \
+        getattr(red, "orders_side_lane", None) is not None and red.orders_side_lane(ex):
+      loss, correct = ex.train_step(images, idx, self._loss_scale(), red.on_bucket_ready,
+                                    soft_joins=True)
+    else:
+      loss, correct = ex.train_step(images, idx, self._loss_scale(),
+                                    red.on_bucket_ready if red is not None else None)
     if red is not None:
       red.finish()
       if self.deterministic:
