@@ -111,6 +111,25 @@ def test_imagenet_resnet50_native_end_to_end(tmp_path, small_validation):
 
 
 @pytest.mark.gpu
+def test_imagenet_real_data_native_end_to_end(tmp_path, small_validation):
+  """ImageNet driver on a TFRecord tree (1024 + 128 shards of small synthetic JPEGs): worker
+  processes decode / crop / resize, the device prefetcher stages batches, the native engine
+  trains and evaluates."""
+  import subprocess
+  data = tmp_path / "imagenet"
+  r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "make_fake_imagenet.py"),
+                      str(data), "1", "72", "96"], capture_output=True, text=True, timeout=300)
+  assert r.returncode == 0, r.stderr[-2000:]
+  resnet_imagenet_main.define_imagenet_keras_flags()
+  stats = integration.run_synthetic(
+      main=resnet_imagenet_main.run, tmp_root=str(tmp_path), synth=False,
+      extra_flags=["-data_dir", str(data), "-batch_size", "4", "-train_steps", "4", "-num_gpus", "1",
+                   "-dtype", "bf16", "-distribution_strategy", "off", "-log_steps", "1"],
+      max_train=None)
+  assert stats["loss"] > 0 and "eval_loss" in stats and "avg_exp_per_second" in stats
+
+
+@pytest.mark.gpu
 def test_profile_steps_traces_native_kernels(tmp_path, small_validation):
   """`--profile_steps a,b` (`common.py:192-197`) on the native engine: the trace written to
   `model_dir` contains the hand-written kernels."""
