@@ -137,7 +137,7 @@ def sample_distorted_bounding_box(height: int, width: int, bboxes: np.ndarray, r
 def _decode(image_buffer: bytes):
   from PIL import Image  # pylint: disable=import-outside-toplevel
   img = Image.open(io.BytesIO(image_buffer))
-  return img.convert("RGB")
+  return img if img.mode == "RGB" else img.convert("RGB")     # CMYK / grayscale files exist
 
 
 def _decode_crop_and_flip(image_buffer: bytes, bbox: np.ndarray, rng):
@@ -185,11 +185,37 @@ def _mean_image_subtraction(image: np.ndarray, means, num_channels: int) -> np.n
   return image - np.asarray(means, dtype=np.float32).reshape(1, 1, num_channels)
 
 
+def _native_resize():
+  """The C++ crop + bilinear resize (`_dtf_data.crop_resize_bilinear`), or None without the module."""
+  from . import native_loader  # pylint: disable=import-outside-toplevel
+  return native_loader.ext().crop_resize_bilinear if native_loader.available() else None
+
+
 def preprocess_image(image_buffer: bytes, bbox: np.ndarray, output_height: int,
                      output_width: int, num_channels: int, is_training: bool = False,
                      rng=None) -> np.ndarray:
-  """Decodes and preprocesses one image to `[output_height, output_width, C]` float32."""
+  """Decodes and preprocesses one image to `[output_height, output_width, C]` float32.
+
+  Training: random distorted-box crop, random flip, bilinear resize; evaluation: aspect-
+  preserving resize to a short side of 256 and a central crop (`imagenet_preprocessing.py:503-537`);
+  then the channel means are subtracted.  With the native input module the crop, the resize
+  (TensorFlow's legacy bilinear rule, which the reference's `_resize_image` uses), the flip and
+  the mean subtraction are one C++ pass over the decoded image; otherwise PIL does the resize.
+  """
   rng = rng or np.random.default_rng()
+  fast = _native_resize() if num_channels == 3 else None
+  if fast is not None:
+    pixels = np.asarray(_decode(image_buffer))           # uint8 [H, W, 3]
+    height, width = pixels.shape[0], pixels.shape[1]
+    if is_training:
+      y, x, h, w = sample_distorted_bounding_box(height, width, bbox, rng)
+      flip = bool(rng.random() < 0.5)
+      return fast(pixels, y, x, h, w, output_height, output_width, 0, 0, output_height,
+                  output_width, flip, list(_CHANNEL_MEANS))
+    new_h, new_w = _smallest_size_at_least(height, width, _RESIZE_MIN)
+    top, left = (new_h - output_height) // 2, (new_w - output_width) // 2
+    return fast(pixels, 0, 0, height, width, new_h, new_w, top, left, output_height,
+                output_width, False, list(_CHANNEL_MEANS))
   if is_training:
     img = _decode_crop_and_flip(image_buffer, bbox, rng)
     img = _resize_image(img, output_height, output_width)

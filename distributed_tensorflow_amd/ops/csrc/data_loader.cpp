@@ -11,6 +11,7 @@
 //
 // No GPU code here; the buffers these functions fill are pinned host tensors that the device
 // prefetcher copies on its own stream.
+#include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
@@ -321,6 +322,71 @@ class CifarLoader {
 
 }  // namespace
 
+// Bilinear resize of a crop of a decoded uint8 HWC image to float32, fused with the horizontal
+// flip and the per-channel mean subtraction of the ImageNet pipeline.  Sampling follows the
+// legacy TensorFlow rule the reference relies on (`tf.compat.v1.image.resize(...,
+// align_corners=False)`, `imagenet_preprocessing.py:483-500`): source coordinate = output index
+// * (input size / output size), the two nearest samples per axis, no antialiasing.
+//   out[i][j] = resized(src[y:y+h, x:x+w] -> [rh, rw])[i + top][j + left] - mean
+// with the flip applied to the output columns.
+py::array_t<float> crop_resize_bilinear(
+    py::array_t<uint8_t, py::array::c_style | py::array::forcecast> src, int y, int x, int h, int w,
+    int rh, int rw, int top, int left, int out_h, int out_w, bool flip,
+    const std::vector<float>& means) {
+  if (src.ndim() != 3) throw std::invalid_argument("crop_resize_bilinear: image must be [H, W, C]");
+  const int H = (int)src.shape(0), W = (int)src.shape(1), C = (int)src.shape(2);
+  if (y < 0 || x < 0 || h <= 0 || w <= 0 || y + h > H || x + w > W)
+    throw std::invalid_argument("crop_resize_bilinear: crop box outside the image");
+  if (rh <= 0 || rw <= 0 || top < 0 || left < 0 || top + out_h > rh || left + out_w > rw)
+    throw std::invalid_argument("crop_resize_bilinear: output window outside the resized image");
+  if (!means.empty() && (int)means.size() != C)
+    throw std::invalid_argument("crop_resize_bilinear: one mean per channel");
+  py::array_t<float> out({out_h, out_w, C});
+  const uint8_t* in = src.data();
+  float* o = out.mutable_data();
+  {
+    py::gil_scoped_release nogil;
+    const float sy = (float)h / (float)rh, sx = (float)w / (float)rw;
+    // columns: element offsets (relative to the crop's first column) and weights, once per image
+    std::vector<int> x0(out_w), x1(out_w);
+    std::vector<float> fx(out_w);
+    for (int j = 0; j < out_w; ++j) {
+      const float f = (float)(j + left) * sx;
+      const int lo = (int)f;
+      x0[j] = std::min(lo, w - 1) * C;
+      x1[j] = std::min(lo + 1, w - 1) * C;
+      fx[j] = f - (float)lo;
+    }
+    std::vector<float> mean(C, 0.f);
+    for (int k = 0; k < C && k < (int)means.size(); ++k) mean[k] = means[k];
+    // per output row: blend the two source rows over the crop's width (a contiguous, vectorisable
+    // sweep), then pick / blend the two neighbouring columns of every output pixel
+    std::vector<float> line((size_t)w * C);
+    for (int i = 0; i < out_h; ++i) {
+      const float f = (float)(i + top) * sy;
+      const int lo = (int)f;
+      const float fy = f - (float)lo;
+      const uint8_t* r0 = in + ((size_t)(y + std::min(lo, h - 1)) * W + x) * C;
+      const uint8_t* r1 = in + ((size_t)(y + std::min(lo + 1, h - 1)) * W + x) * C;
+      float* t = line.data();
+      const int n = w * C;
+      for (int e = 0; e < n; ++e) {
+        const float a = (float)r0[e];
+        t[e] = a + ((float)r1[e] - a) * fy;
+      }
+      float* orow = o + (size_t)i * out_w * C;
+      for (int j = 0; j < out_w; ++j) {
+        const float* a = t + x0[j];
+        const float* b = t + x1[j];
+        float* dst = orow + (size_t)(flip ? out_w - 1 - j : j) * C;
+        const float wx = fx[j];
+        for (int k = 0; k < C; ++k) dst[k] = a[k] + (b[k] - a[k]) * wx - mean[k];
+      }
+    }
+  }
+  return out;
+}
+
 PYBIND11_MODULE(_dtf_data, m) {
   m.doc() = "native host-side input pipeline (CIFAR-10 loader, TFRecord reader, CRC-32C)";
   m.def("crc32c", [](py::bytes b, uint32_t crc) {
@@ -332,6 +398,10 @@ PYBIND11_MODULE(_dtf_data, m) {
     return masked_crc32c(reinterpret_cast<const uint8_t*>(s.data()), s.size());
   });
   m.def("tfrecord_read_all", &tfrecord_read_all, py::arg("path"), py::arg("verify") = true);
+  m.def("crop_resize_bilinear", &crop_resize_bilinear, py::arg("image"), py::arg("y"), py::arg("x"),
+        py::arg("h"), py::arg("w"), py::arg("resized_h"), py::arg("resized_w"), py::arg("top"),
+        py::arg("left"), py::arg("out_h"), py::arg("out_w"), py::arg("flip") = false,
+        py::arg("means") = std::vector<float>());
   py::class_<CifarLoader>(m, "CifarLoader")
       .def(py::init<const std::vector<std::string>&, bool, int, int, int, uint64_t, int, bool, int>(),
            py::arg("files"), py::arg("is_training"), py::arg("batch_size"),

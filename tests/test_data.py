@@ -229,3 +229,55 @@ def test_native_crc_and_tfrecord_reader(tmp_path):
   with pytest.raises(RuntimeError, match="checksum"):
     native_loader.read_tfrecords(path)
   assert len(native_loader.read_tfrecords(path, verify=False)) == 4
+
+
+def _tf_legacy_bilinear(crop, oh, ow):
+  """`tf.compat.v1.image.resize(..., align_corners=False)`: src = dst * in / out, two taps."""
+  H, W, _ = crop.shape
+  ys, xs = np.arange(oh) * (H / oh), np.arange(ow) * (W / ow)
+  y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+  y1, x1 = np.minimum(y0 + 1, H - 1), np.minimum(x0 + 1, W - 1)
+  fy, fx = (ys - y0)[:, None, None], (xs - x0)[None, :, None]
+  t0 = crop[y0][:, x0] * (1 - fx) + crop[y0][:, x1] * fx
+  t1 = crop[y1][:, x0] * (1 - fx) + crop[y1][:, x1] * fx
+  return t0 * (1 - fy) + t1 * fy
+
+
+def test_native_crop_resize_matches_tensorflow_legacy_bilinear():
+  from distributed_tensorflow_amd.data import native_loader
+  if not native_loader.available():
+    pytest.skip("native input module not built")
+  ext = native_loader.ext()
+  rng = np.random.default_rng(3)
+  img = rng.integers(0, 256, size=(97, 130, 3), dtype=np.uint8)
+  means = [123.68, 116.78, 103.94]
+  # training flavour: crop box -> 64 x 48, with and without flip; an upscaling case too
+  for (y, x, h, w, oh, ow) in [(5, 7, 80, 100, 64, 48), (0, 0, 97, 130, 224, 224), (10, 20, 33, 31, 17, 90)]:
+    ref = _tf_legacy_bilinear(img[y:y + h, x:x + w].astype(np.float64), oh, ow) - np.asarray(means)
+    out = ext.crop_resize_bilinear(img, y, x, h, w, oh, ow, 0, 0, oh, ow, False, means)
+    assert out.dtype == np.float32 and out.shape == (oh, ow, 3)
+    assert np.abs(out - ref).max() < 0.02
+    flipped = ext.crop_resize_bilinear(img, y, x, h, w, oh, ow, 0, 0, oh, ow, True, means)
+    assert np.abs(flipped - ref[:, ::-1]).max() < 0.02
+  # evaluation flavour: the whole image resized to 150 x 201, central 112 x 112 window
+  full = _tf_legacy_bilinear(img.astype(np.float64), 150, 201)
+  top, left = (150 - 112) // 2, (201 - 112) // 2
+  out = ext.crop_resize_bilinear(img, 0, 0, 97, 130, 150, 201, top, left, 112, 112, False, [])
+  assert np.abs(out - full[top:top + 112, left:left + 112]).max() < 0.02
+  with pytest.raises(ValueError):
+    ext.crop_resize_bilinear(img, 90, 0, 20, 20, 8, 8, 0, 0, 8, 8, False, [])
+
+
+def test_imagenet_preprocess_shapes_and_mean_subtraction():
+  """Train / eval preprocessing of a constant-colour JPEG: every output pixel is the colour minus
+  the channel means, whatever the crop, flip and resize did."""
+  from PIL import Image
+  buf = io.BytesIO()
+  Image.new("RGB", (320, 200), (200, 100, 50)).save(buf, format="JPEG", quality=95)
+  bbox = np.zeros((0, 4), dtype=np.float32)
+  want = np.array([200, 100, 50]) - np.array([123.68, 116.78, 103.94])
+  for training in (True, False):
+    out = imnet.preprocess_image(buf.getvalue(), bbox, 224, 224, 3, training,
+                                                  np.random.default_rng(0))
+    assert out.shape == (224, 224, 3) and out.dtype == np.float32
+    assert np.abs(out - want).max() < 3.0         # JPEG rounding of a flat colour
