@@ -370,3 +370,32 @@ def test_torchrun_launch_with_agent_store(tmp_path):
                       str(port), str(script)], env=env, capture_output=True, text=True, timeout=300)
   assert r.returncode == 0, r.stderr[-3000:]
   assert (tmp_path / "ok").exists()
+
+
+def test_horovodrun_command_line(tmp_path):
+  """`horovodrun -np 2 -H localhost:2 python script.py` (`README.md:239-250`): host-major ranks,
+  the Horovod facade sees size 2, gradients are averaged."""
+  from distributed_tensorflow_amd import horovodrun
+  assert horovodrun.parse_hosts("a:4,b:4", 6) == [("a", 4), ("b", 4)]
+  assert horovodrun.plan([("a", 4), ("b", 4)], 6) == [("a", 0, 4), ("b", 4, 2)]
+  with pytest.raises(ValueError):
+    horovodrun.parse_hosts("a:1", 2)
+  script = tmp_path / "hv.py"
+  script.write_text("import sys, os, json\nsys.path.insert(0, %r)\nimport torch\n" % ROOT + textwrap.dedent("""
+    torch.set_num_threads(1)
+    import distributed_tensorflow_amd.hvd as hvd
+    hvd.init(use_gpu=False)
+    assert hvd.size() == 2 and hvd.local_rank() == hvd.rank()
+    t = hvd.allreduce(torch.tensor([float(hvd.rank() + 1)]), average=True)
+    assert abs(t.item() - 1.5) < 1e-6
+    open(os.path.join(%r, "ok%%d" %% hvd.rank()), "w").write("ok")
+    hvd.shutdown()
+  """ % str(tmp_path)))
+  env = dict(os.environ, OMP_NUM_THREADS="1")
+  for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TF_CONFIG", "MASTER_ADDR", "MASTER_PORT"):
+    env.pop(k, None)
+  r = subprocess.run([os.path.join(ROOT, "horovodrun"), "--start-timeout", "60", "-np", "2", "-H",
+                      "localhost:2", "--verbose", "python", str(script)],
+                     env=env, capture_output=True, text=True, timeout=300)
+  assert r.returncode == 0, r.stderr[-3000:]
+  assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
