@@ -28,6 +28,7 @@ finished; a PS returns once every worker said so - a clean shutdown instead of
 from __future__ import annotations
 
 import datetime
+import os
 import time
 from typing import List, Optional, Tuple
 
@@ -65,6 +66,11 @@ class ParameterServerStrategy(Strategy):
                        "cluster (TF_CONFIG) or DTF_NUM_PS >= 1 from the launcher")
     if task.num_workers < 1:
       raise ValueError("parameter_server strategy needs at least one worker")
+    if task.job == "ps" and os.environ.get("DTF_PS_DEVICE", "").lower() == "cpu":
+      # shard holder in host memory (needs a backend that moves CPU tensors, i.e. gloo): for
+      # rehearsals on a machine with fewer GPUs than ranks, and for models that should not
+      # spend a GPU on holding parameters
+      use_gpu = False
     comm = get_communicator(task, use_gpu=use_gpu)
     super().__init__(comm.device)
     self.comm = comm
@@ -75,6 +81,7 @@ class ParameterServerStrategy(Strategy):
     self._store = comm.store() if comm.world_size > 1 else None
     self._done_sent = False
     self.updates_applied = 0
+    self._host = {}
 
   # -- topology --------------------------------------------------------------------
   @property
@@ -123,6 +130,37 @@ class ParameterServerStrategy(Strategy):
       pass
     return msg
 
+  # -- transfers ---------------------------------------------------------------------
+  # RCCL moves device memory directly.  Any other backend (gloo: parameter server in host
+  # memory like the reference's `/job:ps/.../CPU:0`, or a rehearsal on fewer GPUs than ranks)
+  # gets device tensors staged through pinned host buffers here: gloo's own handling of device
+  # tensors took seconds for the 102 MB of ResNet-50 on the test machine.
+  def _staging(self, t: torch.Tensor) -> Optional[torch.Tensor]:
+    if not t.is_cuda or self.comm.backend == "nccl":
+      return None
+    key = (t.numel(), t.dtype)
+    buf = self._host.get(key)
+    if buf is None:
+      buf = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
+      self._host[key] = buf
+    return buf
+
+  def _send(self, t: torch.Tensor, dst: int):
+    h = self._staging(t)
+    if h is None:
+      self.comm.send(t, dst)
+    else:
+      h.copy_(t.reshape(-1))             # synchronous device-to-host copy
+      self.comm.send(h, dst)
+
+  def _recv(self, t: torch.Tensor, src: int):
+    h = self._staging(t)
+    if h is None:
+      self.comm.recv(t, src)
+    else:
+      self.comm.recv(h, src)
+      t.reshape(-1).copy_(h, non_blocking=False)
+
   # -- worker side -------------------------------------------------------------------
   def _shards(self, store):
     return shard_ranges(store.num_elements, self.num_ps)
@@ -133,9 +171,9 @@ class ParameterServerStrategy(Strategy):
       self._post(k, "pull:%d" % self.comm.rank)
     for k, (a, b) in enumerate(self._shards(store)):
       if b > a:
-        self.comm.recv(store.params[a:b], k)
+        self._recv(store.params[a:b], k)
       if k == 0 and store.num_state_elements:
-        self.comm.recv(store.state, 0)
+        self._recv(store.state, 0)
     store.version += 1
 
   def push(self, store, lr: float, divisor: float = 1.0):
@@ -144,9 +182,9 @@ class ParameterServerStrategy(Strategy):
       self._post(k, "push:%d:%r:%r" % (self.comm.rank, float(lr), float(divisor)))
     for k, (a, b) in enumerate(self._shards(store)):
       if b > a:
-        self.comm.send(store.grads[a:b], k)
+        self._send(store.grads[a:b], k)
       if k == 0 and store.num_state_elements:
-        self.comm.send(store.state, 0)
+        self._send(store.state, 0)
 
   def shutdown(self):
     if self.is_ps_task or self._done_sent or self._store is None:
@@ -177,15 +215,15 @@ class ParameterServerStrategy(Strategy):
       op, src = parts[0], int(parts[1])
       if op == "pull":
         if n:
-          self.comm.send(store.params[a:b], src)
+          self._send(store.params[a:b], src)
         if k == 0 and store.num_state_elements:
-          self.comm.send(store.state, src)
+          self._send(store.state, src)
       elif op == "push":
         lr, divisor = float(parts[2]), float(parts[3])
         if n:
-          self.comm.recv(recv_buf[:n], src)
+          self._recv(recv_buf[:n], src)
         if k == 0 and store.num_state_elements:
-          self.comm.recv(store.state, src)
+          self._recv(store.state, src)
         if n:
           shard.apply_sgd(recv_buf[:n], lr, getattr(opt, "momentum", 0.0), divisor)
         self.updates_applied += 1

@@ -7,18 +7,18 @@ from distributed_tensorflow_amd.parallel.parameter_server import ParameterServer
 from distributed_tensorflow_amd.train.model import Model
 from distributed_tensorflow_amd.train.optimizers import SGD
 st = ParameterServerStrategy(use_gpu=os.environ.get("PS_GPU") == "1")
-m = Model(models.resnet20(), strategy=st, dtype="fp32", device=st.device, executor="torch")
+m = Model(getattr(models, os.environ.get("PS_MODEL", "resnet20"))(), strategy=st, dtype="fp32", device=st.device, executor="torch")
 m.compile(SGD(0.1, momentum=0.9), "sparse_categorical_crossentropy")
 if st.is_ps_task:
   st.serve(m)
 else:
   m._sync_initial_variables()
   t0 = time.time()
-  for i in range(50):
+  for i in range(int(os.environ.get("PS_ITERS", "50"))):
     st.pull(m.store)
   t1 = time.time()
-  for i in range(50):
+  for i in range(int(os.environ.get("PS_ITERS", "50"))):
     st.push(m.store, 0.1, 1.0)
   t2 = time.time()
-  print("pull %.2f ms  push %.2f ms" % ((t1 - t0) * 20, (t2 - t1) * 20), flush=True)
+  print("pull %.2f ms  push %.2f ms" % ((t1 - t0) * 1000 / int(os.environ.get("PS_ITERS", "50")), (t2 - t1) * 1000 / int(os.environ.get("PS_ITERS", "50"))), flush=True)
   st.shutdown()
