@@ -165,16 +165,30 @@ class ParameterServerStrategy(Strategy):
   def _shards(self, store):
     return shard_ranges(store.num_elements, self.num_ps)
 
-  def pull(self, store):
-    """Fetch the current parameters (and moving statistics) from the PS ranks."""
+  def pull(self, store, half: bool = False):
+    """Fetch the current parameters (and moving statistics) from the PS ranks.
+
+    `half`: the worker computes in a 16-bit format, so it asks for bfloat16 parameters - half
+    the bytes per pull, and exactly the values its executor would round the fp32 ones to.  The
+    master copy stays fp32 on the PS (updates are applied there)."""
     for k, (a, b) in enumerate(self._shards(store)):
-      self._post(k, "pull:%d" % self.comm.rank)
+      self._post(k, "pull:%d:%s" % (self.comm.rank, "bf16" if half else "fp32"))
     for k, (a, b) in enumerate(self._shards(store)):
-      if b > a:
+      if b > a and half:
+        buf = self._half_buf(b - a, store.device)
+        self._recv(buf, k)
+        store.params[a:b].copy_(buf)
+      elif b > a:
         self._recv(store.params[a:b], k)
       if k == 0 and store.num_state_elements:
         self._recv(store.state, 0)
     store.version += 1
+
+  def _half_buf(self, n: int, device) -> torch.Tensor:
+    key = ("half", n, str(device))
+    if key not in self._host:
+      self._host[key] = torch.empty(n, dtype=torch.bfloat16, device=device)
+    return self._host[key]
 
   def push(self, store, lr: float, divisor: float = 1.0):
     """Send this worker's gradients; the PS applies them on arrival."""
@@ -214,7 +228,11 @@ class ParameterServerStrategy(Strategy):
       parts = msg.split(":")
       op, src = parts[0], int(parts[1])
       if op == "pull":
-        if n:
+        if n and len(parts) > 2 and parts[2] == "bf16":
+          buf = self._half_buf(n, store.device)
+          buf.copy_(store.params[a:b])
+          self._send(buf, src)
+        elif n:
           self._send(store.params[a:b], src)
         if k == 0 and store.num_state_elements:
           self._send(store.state, src)

@@ -188,7 +188,7 @@ class Model:
     idx = self._class_indices(labels.to(self.device))
     if st is not None and not st.synchronous:
       # asynchronous parameter server: pull -> compute -> push
-      st.pull(self.store)
+      st.pull(self.store, half=self.dtype in ("bf16", "fp16"))
       ex.params_updated()
       scale = self._loss_scale()
       loss, correct = ex.train_step(images, idx, scale)

@@ -399,3 +399,33 @@ def test_horovodrun_command_line(tmp_path):
                      env=env, capture_output=True, text=True, timeout=300)
   assert r.returncode == 0, r.stderr[-3000:]
   assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_parameter_server_half_precision_pull(tmp_path):
+  """A 16-bit worker asks for bfloat16 parameters: it receives exactly the bf16 rounding of the
+  fp32 master copy, which stays on the ps task and keeps receiving fp32 updates."""
+  body = COMMON + """
+from distributed_tensorflow_amd.parallel.parameter_server import ParameterServerStrategy
+strat = ParameterServerStrategy(use_gpu=False)
+m = Model(models.resnet20(), strategy=strat, dtype="fp32", seed=7)
+m.compile(SGD(0.1, momentum=0.9), "sparse_categorical_crossentropy")
+if strat.is_ps_task:
+  n = strat.serve(m)
+  save({"updates": n, "psum": m.store.params.double().sum().item()})
+else:
+  expect = m.store.params.to(torch.bfloat16).float()      # same seed as the ps task
+  m.store.params.zero_()
+  strat.pull(m.store, half=True)
+  ok_half = bool(torch.equal(m.store.params, expect))
+  m.store.params.zero_()
+  strat.pull(m.store)
+  ok_full = bool(torch.equal(m.store.params.to(torch.bfloat16).float(), expect)) and \\
+      not torch.equal(m.store.params, expect)
+  m.store.grads.fill_(0.5)
+  strat.push(m.store, 0.1, 1.0)
+  strat.shutdown()
+  save({"ok_half": ok_half, "ok_full": ok_full})
+"""
+  res = _run_ranks(tmp_path, body, 2, num_ps=1)
+  assert res[0]["updates"] == 1
+  assert res[1]["ok_half"] and res[1]["ok_full"]
