@@ -144,9 +144,24 @@ class DevicePrefetcher:
   def __len__(self):
     return len(self.loader)
 
+  def _start_workers(self):
+    """`iter(loader)`, which forks the worker processes.  The parent may hold GPU objects that
+    are only waiting for the garbage collector (executor plans, streams, events of an earlier
+    model); a collection inside a forked child would run their destructors there, and a HIP
+    call in a forked child aborts it.  So the parent collects first and freezes what is left
+    for the moment of the fork: the children inherit only permanent objects."""
+    import gc  # pylint: disable=import-outside-toplevel
+    gc.collect()
+    gc.freeze()
+    try:
+      return iter(self.loader)
+    finally:
+      gc.unfreeze()
+
   def __iter__(self):
+    it = self._start_workers()
     if self.device.type != "cuda":
-      for images, labels in self.loader:
+      for images, labels in it:
         yield images, labels
       return
     stream = torch.cuda.Stream(self.device)
@@ -155,7 +170,7 @@ class DevicePrefetcher:
 
     def producer():
       try:
-        for images, labels in self.loader:
+        for images, labels in it:
           if stop.is_set():
             return
           if self.delay_ms:
