@@ -26,3 +26,7 @@ __version__ = "0.1.0"
 import os as _os
 
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# RCCL (and device-tensor sharing between processes) exchange memory handles through the
+# dmabuf IPC path; hosts whose driver only supports that path need the legacy mode switched off
+# or `hipIpcGetMemHandle` fails with "invalid argument" as soon as two ranks talk.
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
