@@ -54,6 +54,12 @@ def main() -> int:
                        "all-reduce per bucket on the communication stream) in a one-rank group")
   ap.add_argument("--executor", default="hip", choices=["hip", "torch"])
   a = ap.parse_args()
+  # stdout carries the result line and nothing else: libraries write there too (RCCL prints a
+  # five-line version banner to stdout when a communicator is created), so file descriptor 1 is
+  # pointed at stderr for the duration of the run and the JSON goes to the saved descriptor.
+  sys.stdout.flush()
+  result_fd = os.dup(1)
+  os.dup2(2, 1)
   if os.environ.get("DTF_DEBUG_HANG"):      # dump every thread's stack if still running after N s
     import faulthandler
     faulthandler.dump_traceback_later(float(os.environ["DTF_DEBUG_HANG"]), exit=False)
@@ -163,7 +169,8 @@ def main() -> int:
                    "executor": model.executor_kind, "launch": launch_mode,
                    "final_loss": round(loss_val, 4),
                    "baseline_img_per_sec": baseline_for(a.gpus)}}
-    print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
   if strat is not None:
     strat.barrier()
     from distributed_tensorflow_amd.parallel import comm
