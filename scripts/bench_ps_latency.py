@@ -1,3 +1,7 @@
+"""Pull / push latency of the parameter server for a model's flat buffers (1 ps + 1 worker).
+
+    PS_MODEL=resnet50 PS_ITERS=5 python -m distributed_tensorflow_amd.launch --nproc 2 --num_ps 1 scripts/bench_ps_latency.py
+"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,6 +1,6 @@
 """Compares activations and activation gradients of the HIP engine with the torch executors."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from distributed_tensorflow_amd import models
 from distributed_tensorflow_amd.engine.params import ParamStore

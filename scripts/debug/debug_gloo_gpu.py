@@ -1,3 +1,4 @@
+"""Two gloo ranks exchanging device tensors on one GPU (start with the launcher, 2 ranks)."""
 import os, sys, torch, torch.distributed as dist, datetime, time
 rank=int(os.environ["RANK"]); world=int(os.environ["WORLD_SIZE"])
 print("rank",rank,"start",flush=True)

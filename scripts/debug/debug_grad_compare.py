@@ -1,6 +1,6 @@
 """Prints per-variable gradient agreement: HIP(bf16) vs torch(fp32) and torch(bf16) vs torch(fp32)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from distributed_tensorflow_amd import models
 from distributed_tensorflow_amd.engine.params import ParamStore

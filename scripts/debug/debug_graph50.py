@@ -1,5 +1,6 @@
+"""ResNet-50: eager launch vs hipGraph replay of the native step, with timings."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from distributed_tensorflow_amd import models
 from distributed_tensorflow_amd.engine.params import ParamStore

@@ -1,7 +1,7 @@
 """Step time of the native ResNet-50 executor with different ways of issuing the per-bucket
 collective (one-rank RCCL group): isolates what the reducer adds to a single-GPU step."""
 import os, sys, time, tempfile
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.distributed as dist
 from distributed_tensorflow_amd import models

@@ -1,7 +1,7 @@
 """One-rank RCCL rehearsal of the reducer path with a stack dump if it stalls."""
 import faulthandler, os, sys
 faulthandler.dump_traceback_later(int(os.environ.get("DTF_DUMP_AFTER", "60")), exit=True)
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["DTF_REHEARSE_COLLECTIVES"] = "1"
 import torch
 from distributed_tensorflow_amd import models
