@@ -60,6 +60,7 @@ class GradientReducer:
     self._stream = None            # None: not decided yet; False: torch.distributed's own stream
     self._stream_pending = False
     self._side = None              # the executor's side lane, when it orders its results here
+    self._executor = None          # set by orders_side_lane()
     self.bytes_reduced = 0
     self.collectives_launched = 0
 
@@ -149,7 +150,7 @@ class GradientReducer:
       # gradients enqueued so far, the collective is issued as a blocking-API call *on that
       # stream*, and finish() makes the compute stream wait for the communication stream
       cs.wait_stream(torch.cuda.current_stream(g.device))
-      ex = getattr(self, "_executor", None)
+      ex = self._executor
       if ex is not None:
         if self._side is None:
           self._side = ex.side_stream()          # None until the side lane has been used
