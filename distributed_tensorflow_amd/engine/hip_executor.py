@@ -305,9 +305,26 @@ class HipExecutor:
     if training and (self._bn_stats_off or self._bn_bwd_stats_off):
       plan.add("memset", dict(ptr=self.bn_stats.data_ptr(), nbytes=self.bn_stats.numel() * 4),
                "zero_bn_stats")
+    folded = {} if training else self._plan_bn_fold(plan)
+    deferred = {b.inputs[0] for b in folded.values()}
     for op in spec.ops:
       at = op.attrs
       x = acts[op.inputs[0]]
+      if op.kind == "conv" and op.output in deferred:
+        continue                       # launched at its BatchNorm's position, see below
+      if op.kind == "bn" and op.name in folded:
+        # inference: conv + BatchNorm (+ residual) (+ ReLU) is one launch, the intermediate
+        # tensor is never written
+        conv = self._producer[op.inputs[0]]
+        g = self.geoms[conv.name]
+        d = g.fwd(acts[conv.inputs[0]].data_ptr(), self._wf_ptr(conv.name),
+                  acts[op.output].data_ptr(), bias=self._fold_ptr[op.name][1])
+        d["scale"] = self._fold_ptr[op.name][0]
+        d["relu"] = int(at["relu"])
+        if len(op.inputs) > 1:
+          d["addend"] = acts[op.inputs[1]].data_ptr()
+        self._add(plan, "conv", d, conv.name + "+" + op.name)
+        continue
       if op.kind == "conv":
         g = self.geoms[op.name]
         st = self._stats_of_conv.get(op.output) if training else None
@@ -361,6 +378,55 @@ class HipExecutor:
         dlogits=self.dlogits.data_ptr() if training else None, accum=self.accum.data_ptr(),
         N=N, C=spec.num_classes, ld=ld, grad_scale=1.0 / N,
         grad_scale_dev=self.loss_scale_dev.data_ptr()), "softmax_xent")
+
+  def _plan_bn_fold(self, plan) -> Dict:
+    """Inference: BatchNorm layers whose input comes straight from a convolution are folded into
+    that convolution's epilogue (K6 of the kernel inventory: folded scale / shift, + ReLU, + Add;
+    reference evaluation pass `image_classification/resnet_imagenet_main.py:256-259`).  Adds the
+    launch that derives scale / shift from the current parameters and moving statistics, and
+    returns {BatchNorm name: op} of the folded layers."""
+    import struct
+    spec, acts = self.spec, self.acts
+    if os.environ.get("DTF_EVAL_FOLD_BN", "1") == "0":
+      return {}
+    consumers: Dict[str, int] = {}
+    for op in spec.ops:
+      for t in op.inputs:
+        consumers[t] = consumers.get(t, 0) + 1
+    self._producer = {o.output: o for o in spec.ops}
+    folded = {}
+    for b in spec.ops:
+      if b.kind != "bn":
+        continue
+      src = self._producer.get(b.inputs[0])
+      c = b.attrs["channels"]
+      if (src is not None and src.kind == "conv" and consumers.get(b.inputs[0], 0) == 1
+          and acts[b.inputs[0]].shape == acts[b.output].shape and acts[b.output].shape[-1] == c
+          and b.inputs[0] != spec.logits_name):
+        folded[b.name] = b
+    if not folded:
+      return {}
+    tot = sum(b.attrs["channels"] for b in folded.values())
+    self.bn_folded = self._alloc((2 * tot,), torch.float32)
+    ent = self.store.entries
+    raw = bytearray()
+    self._fold_ptr: Dict[str, Tuple[int, int]] = {}
+    o = 0
+    for b in folded.values():
+      c = b.attrs["channels"]
+      raw += struct.pack("<5qif", ent[b.name + "/gamma"].offset, ent[b.name + "/beta"].offset,
+                         ent[b.name + "/moving_mean"].offset,
+                         ent[b.name + "/moving_variance"].offset, o, c, float(b.attrs["eps"]))
+      base = self.bn_folded.data_ptr() + 4 * o
+      self._fold_ptr[b.name] = (base, base + 4 * c)
+      o += 2 * c
+    assert len(raw) == native.ext().bn_fold_desc_size() * len(folded)
+    self._fold_descs = torch.frombuffer(raw, dtype=torch.uint8).to(self.device)
+    self._keep.append(self._fold_descs)
+    plan.add("bn_fold", dict(params=self.store.params.data_ptr(),
+                             state=self.store.state.data_ptr(), out=self.bn_folded.data_ptr(),
+                             descs=self._fold_descs.data_ptr(), nlayers=len(folded)), "bn_fold")
+    return folded
 
   # ---- backward ----------------------------------------------------------------------------
   def _build_backward(self, consumers: Dict[str, int]):

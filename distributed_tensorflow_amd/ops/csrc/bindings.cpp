@@ -55,6 +55,8 @@ ConvParams conv_from_dict(const py::dict& d) {
   p.addend = ptr<const bf16_t>(d, "addend", false);
   p.addend_mask = ptr<const uint8_t>(d, "addend_mask", false);
   p.bias = ptr<const float>(d, "bias", false);
+  p.scale = ptr<const float>(d, "scale", false);
+  p.relu = get_or<int>(d, "relu", 0);
   p.stats = ptr<float>(d, "stats", false);
   p.stats_replicas = get_or<int>(d, "stats_replicas", 0);
   p.stats_y = ptr<const bf16_t>(d, "stats_y", false);
@@ -145,6 +147,12 @@ Launch make_op(const std::string& kind, const py::dict& d) {
       launch_bn_fwd_train(y, res, z, mask, gamma, beta, mm, mv, smean, sinv, scale, shift, ws,
                           fused, P, C, eps, mom, relu, s);
     };
+  }
+  if (kind == "bn_fold") {
+    auto params = ptr<const float>(d, "params"); auto state = ptr<const float>(d, "state");
+    auto out = ptr<float>(d, "out"); auto descs = ptr<const uint8_t>(d, "descs");
+    const int n = get<int>(d, "nlayers");
+    return [=](hipStream_t s) { launch_bn_fold(params, state, out, descs, n, s); };
   }
   if (kind == "bn_infer") {
     auto y = ptr<const bf16_t>(d, "y"); auto res = ptr<const bf16_t>(d, "res", false);
@@ -508,6 +516,7 @@ PYBIND11_MODULE(_dtf_native, m) {
   m.def("fastdiv_check", [](uint32_t n, uint32_t d) { return fd_div(n, make_fastdiv(d)); });
   m.def("pack_desc_size", []() { return (int)sizeof(PackDesc); });
   m.def("bn_workspace_floats", []() { return bn_workspace_floats(); });
+  m.def("bn_fold_desc_size", []() { return bn_fold_desc_size(); });
   m.attr("PACK_PER_BLOCK") = 256 * 8;
   m.attr("arch") = "gfx950";
   py::class_<Plan>(m, "Plan")

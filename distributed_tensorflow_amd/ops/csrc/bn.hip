@@ -442,6 +442,28 @@ __global__ __launch_bounds__(TPB) void mask_apply_kernel(const bf16_t* __restric
   }
 }
 
+// Inference: scale = gamma / sqrt(moving_var + eps), shift = beta - moving_mean * scale for every
+// BatchNorm layer of a model in one launch (one block per layer), consumed by the folded
+// convolution epilogue.  Descriptor: five int64 element offsets (gamma and beta in `params`,
+// moving mean and variance in `state`, scale in `out`; shift follows at out + C), then C and eps.
+struct BnFoldDesc {
+  long long gamma, beta, mm, mv, out;
+  int C;
+  float eps;
+};
+
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ params,
+                                                      const float* __restrict__ state,
+                                                      float* __restrict__ out,
+                                                      const BnFoldDesc* __restrict__ descs) {
+  const BnFoldDesc d = descs[blockIdx.x];
+  for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+    const float sc = params[d.gamma + c] * rsqrtf(state[d.mv + c] + d.eps);
+    out[d.out + c] = sc;
+    out[d.out + d.C + c] = params[d.beta + c] - state[d.mm + c] * sc;
+  }
+}
+
 void check_channels(int C, int P) {
   if (C < 8 || C > 2048 || (C & (C - 1)))
     throw std::invalid_argument("batch-norm kernels need a power-of-two channel count in [8, 2048]");
@@ -468,6 +490,15 @@ int reduce_grid(int P, int C) {
 }
 
 }  // namespace
+
+int bn_fold_desc_size() { return (int)sizeof(BnFoldDesc); }
+
+void launch_bn_fold(const float* params, const float* state, float* out, const void* descs,
+                    int nlayers, hipStream_t s) {
+  if (nlayers <= 0) return;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(nlayers), dim3(256), 0, s, params, state, out,
+                     reinterpret_cast<const BnFoldDesc*>(descs));
+}
 
 size_t bn_workspace_floats() { return (size_t)MAX_PARTIAL_BLOCKS * 2 * 2048; }
 

@@ -84,13 +84,18 @@ constexpr int GENERIC = 0, POINTWISE_MODE = 1, TAPLOOP = 2;
 
 // Second launch-bound argument = waves per SIMD the register allocation must allow: 4 blocks
 // of 4 waves per CU (64 accumulator registers + ~60 others fit the 128-register budget).
-// BSTATS selects the backward flavour of the fused statistics (sum g, sum g*y; see ConvParams)
-// at compile time: the extra loads and registers of that epilogue stay out of the forward
-// instantiations.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool BSTATS = false>
+// EPI selects the epilogue flavour at compile time, so that the extra loads and registers of the
+// special ones stay out of the training-forward instantiations:
+//   EPI_PLAIN   bias / addend / forward BatchNorm statistics (runtime options)
+//   EPI_BSTATS  backward flavour of the fused statistics (sum g, sum g*y; see ConvParams)
+//   EPI_INFER   folded BatchNorm for inference: acc * scale + bias (+ addend), optional ReLU
+constexpr int EPI_PLAIN = 0, EPI_BSTATS = 1, EPI_INFER = 2;
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int EPI = EPI_PLAIN>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 4)
 void conv_igemm_kernel(const ConvParams p) {
   constexpr bool POINTWISE = MODE == POINTWISE_MODE;
+  constexpr bool BSTATS = EPI == EPI_BSTATS;
   constexpr int NW = WAVES_M * WAVES_N;             // waves per block: 4, or 8 for the 256x128 tile
   constexpr int RPP = 16 * NW;                      // tile rows filled per pass (16 per wave)
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -318,6 +323,21 @@ void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
   for (int c = 0; c < CPL; ++c)
     bias[c] = (p.bias != nullptr && co0 + c < p.Cout) ? p.bias[co0 + c] : 0.f;
+  if constexpr (EPI == EPI_INFER) {
+    // tile nr of a lane holds channels co0 + 4*nr .. co0 + 4*nr + 3
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+      float sc[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        sc[e] = (co0 + nr * 4 + e < p.Cout) ? p.scale[co0 + nr * 4 + e] : 0.f;
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[nr][mr][e] *= sc[e];
+    }
+  }
+  const bool do_relu = EPI == EPI_INFER && p.relu != 0;
   const bool vec_ok = (p.ldc % 8 == 0);
   // fused batch-norm statistics: [0, CPL) sums, [CPL, 2*CPL) sums of squares of this lane's
   // channels over its MR pixels (the host guarantees the vector store path in that case)
@@ -365,10 +385,14 @@ void conv_igemm_kernel(const ConvParams p) {
             v4 += __uint_as_float(a.z << 16); v5 += __uint_as_float(a.z & 0xffff0000u);
             v6 += __uint_as_float(a.w << 16); v7 += __uint_as_float(a.w & 0xffff0000u);
           }
+          if (do_relu) {
+            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+            v4 = fmaxf(v4, 0.f); v5 = fmaxf(v5, 0.f); v6 = fmaxf(v6, 0.f); v7 = fmaxf(v7, 0.f);
+          }
           u32x4 o;
           o.x = pack2bf(v0, v1); o.y = pack2bf(v2, v3); o.z = pack2bf(v4, v5); o.w = pack2bf(v6, v7);
           *reinterpret_cast<u32x4*>(optr + h * 8) = o;
-          if (p.stats) {
+          if (EPI != EPI_INFER && p.stats) {
             const uint32_t w[4] = {o.x, o.y, o.z, o.w};
             if constexpr (BSTATS) {                  // sum g, sum g * y  (g = masked output)
               const u32x4 yq = *reinterpret_cast<const u32x4*>(p.stats_y + obase + co0 + h * 8);
@@ -402,7 +426,7 @@ void conv_igemm_kernel(const ConvParams p) {
             if (co0 + h * 8 + c < p.Cout) {
               float x = vv[c];
               if (aptr) x += bf2f(aptr[h * 8 + c]);
-              optr[h * 8 + c] = f2bf(x);
+              optr[h * 8 + c] = f2bf(do_relu ? fmaxf(x, 0.f) : x);
             }
           }
         }
@@ -422,11 +446,14 @@ void conv_igemm_kernel(const ConvParams p) {
           v0 += __uint_as_float(a.x << 16); v1 += __uint_as_float(a.x & 0xffff0000u);
           v2 += __uint_as_float(a.y << 16); v3 += __uint_as_float(a.y & 0xffff0000u);
         }
+        if (do_relu) {
+          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+        }
         u32x2 o;
         o.x = pack2bf(v0, v1);
         o.y = pack2bf(v2, v3);
         *reinterpret_cast<u32x2*>(optr) = o;
-        if (p.stats) {
+        if (EPI != EPI_INFER && p.stats) {
           const uint32_t w[2] = {o.x, o.y};
           if constexpr (BSTATS) {
             const u32x2 yq = *reinterpret_cast<const u32x2*>(p.stats_y + obase + co0);
@@ -460,13 +487,13 @@ void conv_igemm_kernel(const ConvParams p) {
           if (co0 + c < p.Cout) {
             float x = vv[c];
             if (aptr) x += bf2f(aptr[c]);
-            optr[c] = f2bf(x);
+            optr[c] = f2bf(do_relu ? fmaxf(x, 0.f) : x);
           }
         }
       }
     }
   }
-  if (p.stats) {
+  if (EPI != EPI_INFER && p.stats) {
     constexpr int NV = 2 * CPL;
     constexpr int HALVINGS = NV >= 16 ? 4 : 3;     // NV is 8, 16 or 32
     constexpr int LEFT = NV >> HALVINGS;           // totals per lane afterwards
@@ -486,8 +513,8 @@ void conv_igemm_kernel(const ConvParams p) {
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BSTATS>
-void launch_cfg_stats(const ConvParams& p, hipStream_t stream) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+void launch_cfg_epi(const ConvParams& p, hipStream_t stream) {
   const int tilesN = (p.Cout + BN - 1) / BN;
   const int tilesM = (p.M + BM - 1) / BM;
   const int grid = ((tilesM + 7) / 8) * 8 * tilesN;
@@ -496,20 +523,21 @@ void launch_cfg_stats(const ConvParams& p, hipStream_t stream) {
                          p.OH == p.H && p.OW == p.W && p.OHfull == p.OH && p.OWfull == p.OW &&
                          p.Ctap <= p.Cpix;
   if (pointwise)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, POINTWISE_MODE, BSTATS>),
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, POINTWISE_MODE, EPI>),
                        dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
   else if (p.Ctap % BK == 0)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, TAPLOOP, BSTATS>), dim3(grid),
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, TAPLOOP, EPI>), dim3(grid),
                        dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, GENERIC, BSTATS>), dim3(grid),
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, GENERIC, EPI>), dim3(grid),
                        dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 void launch_cfg(const ConvParams& p, hipStream_t stream) {
-  if (p.stats_y) launch_cfg_stats<BM, BN, WAVES_M, WAVES_N, true>(p, stream);
-  else launch_cfg_stats<BM, BN, WAVES_M, WAVES_N, false>(p, stream);
+  if (p.scale) launch_cfg_epi<BM, BN, WAVES_M, WAVES_N, EPI_INFER>(p, stream);
+  else if (p.stats_y) launch_cfg_epi<BM, BN, WAVES_M, WAVES_N, EPI_BSTATS>(p, stream);
+  else launch_cfg_epi<BM, BN, WAVES_M, WAVES_N, EPI_PLAIN>(p, stream);
 }
 
 }  // namespace
@@ -531,6 +559,12 @@ void validate_conv_params(const ConvParams& p) {
   if (p.addend_mask) {
     if (!p.addend) fail("addend_mask without addend");
     if (p.Cout % 8 || p.ldc % 8) fail("a masked addend needs Cout and ldc to be multiples of 8");
+  }
+  if (p.scale) {
+    if (!p.bias) fail("the inference epilogue needs scale and bias (shift) together");
+    if (p.stats || p.addend_mask) fail("the inference epilogue takes no statistics / masked addend");
+  } else if (p.relu) {
+    fail("relu belongs to the inference epilogue (scale)");
   }
   if (p.stats) {
     if (p.stats_replicas <= 0) fail("stats needs a positive replica count");

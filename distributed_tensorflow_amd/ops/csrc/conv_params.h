@@ -13,6 +13,10 @@ struct ConvParams {
   // elements whose bit is set are added (the ReLU mask of a residual branch's gradient)
   const uint8_t* addend_mask = nullptr;
   const float* bias = nullptr;     // optional per-output-channel bias
+  // Inference epilogue (folded BatchNorm): out = relu?(acc * scale[co] + bias[co] (+ addend)).
+  // `scale` selects it; `bias` then carries the shift and `relu` the activation.
+  const float* scale = nullptr;
+  int relu = 0;
   // optional fused batch-norm statistics: per-channel sum / sum of squares of the (bf16
   // rounded) output, added atomically into replica (m-tile % replicas) of
   // stats[replicas][2][Cout]; the buffer is zeroed by the caller

@@ -11,6 +11,10 @@ void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, uint8_t*
                          float* save_mean, float* save_invstd, float* scale, float* shift,
                          float* ws, int fused_replicas, int P, int C, float eps, float momentum,
                          int relu, hipStream_t s);
+// Folded inference constants of every BatchNorm layer (descriptor layout: see bn.hip).
+int bn_fold_desc_size();
+void launch_bn_fold(const float* params, const float* state, float* out, const void* descs,
+                    int nlayers, hipStream_t s);
 void launch_bn_infer(const bf16_t* y, const bf16_t* res, bf16_t* z, const float* gamma,
                      const float* beta, const float* mm, const float* mv, int P, int C, float eps,
                      int relu, hipStream_t s);

@@ -77,7 +77,43 @@ def test_resnet20_matches_reference():
 
 
 def test_resnet50_small_batch_matches_reference():
-  _compare(models.resnet50(), 8, packs=4)
+  hx, tx, st_h, st_t, x, y, _ = _compare(models.resnet50(), 8, packs=4)
+  le, ce = hx.eval_step(x, y)
+  lt, ct = tx.eval_step(x, y)
+  assert le.item() == pytest.approx(lt.item(), rel=5e-2, abs=5e-2)
+
+
+@pytest.mark.parametrize("name,batch", [("resnet20", 16), ("resnet50", 8)])
+def test_folded_batchnorm_inference_matches_separate_sweeps(monkeypatch, name, batch):
+  """Evaluation folds BatchNorm (+ residual add, + ReLU) into the convolution epilogue; the
+  result must agree with the plan that runs the convolution and the BatchNorm sweep
+  separately, for non-trivial moving statistics, gamma and beta."""
+  from distributed_tensorflow_amd.engine.hip_executor import HipExecutor
+  dev = torch.device("cuda")
+  spec = getattr(models, name)()
+  g = torch.Generator().manual_seed(3)
+  H, W, C = spec.input_shape
+  x = (torch.randn(batch, H, W, C, generator=g) * 60 + 120).to(dev)
+  y = torch.randint(0, spec.num_classes, (batch,), generator=g).to(dev)
+  st = ParamStore(spec, dev, 0)
+  for e in st.entries.values():
+    v = st.view(e.spec.name)
+    if e.spec.var == "moving_variance":
+      v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+    elif e.spec.var in ("moving_mean", "beta"):
+      v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+    elif e.spec.var == "gamma":
+      v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+  outs = []
+  for fold in ("1", "0"):
+    monkeypatch.setenv("DTF_EVAL_FOLD_BN", fold)
+    ex = HipExecutor(spec, st, batch, "bf16", st.make_buckets(1), use_graph=False)
+    loss, correct = ex.eval_step(x, y)
+    probs = ex.predict(x)
+    outs.append((loss.item(), probs.float().cpu(), ex.eval_plan.size()))
+  assert outs[0][2] < outs[1][2]                      # the folded plan has fewer launches
+  assert outs[0][0] == pytest.approx(outs[1][0], rel=3e-2, abs=3e-2)
+  assert torch.allclose(outs[0][1], outs[1][1], atol=3e-2)
 
 
 def test_training_reduces_loss_and_graph_replay_matches_eager():
