@@ -178,6 +178,25 @@ class HipExecutor:
     # ---- packed weights ------------------------------------------------------------------
     self._plan_weight_packing()
 
+    # ---- BatchNorm + ReLU whose only consumer is a max-pool (the ResNet-50 stem): one fused
+    # sweep each way, the full-resolution activation and its gradient are never materialised
+    self._bn_pool: Dict[str, Op] = {}       # BatchNorm name -> max-pool op
+    self._pool_bn: Dict[str, Op] = {}       # max-pool name -> BatchNorm op
+    if os.environ.get("DTF_FUSE_BN_POOL", "1") != "0":
+      by_input: Dict[str, List[Op]] = {}
+      for op in spec.ops:
+        for t in op.inputs:
+          by_input.setdefault(t, []).append(op)
+      for b in spec.ops:
+        c = b.attrs.get("channels", 0)
+        users = by_input.get(b.output, [])
+        if (b.kind == "bn" and b.attrs["relu"] and len(b.inputs) == 1 and len(users) == 1
+            and users[0].kind == "maxpool" and c >= 8 and c & (c - 1) == 0 and c <= 2048
+            and users[0].attrs["stride"] <= users[0].attrs["k"] <= 2 * users[0].attrs["stride"]
+            and users[0].attrs["k"] ** 2 < 255 and b.output != spec.logits_name):
+          self._bn_pool[b.name] = users[0]
+          self._pool_bn[users[0].name] = b
+
     # ---- BatchNorm side buffers -------------------------------------------------------------
     bn_ops = [o for o in spec.ops if o.kind == "bn"]
     tot = sum(o.attrs["channels"] for o in bn_ops)
@@ -204,7 +223,7 @@ class HipExecutor:
           and acts[b.inputs[0]].shape[-1] == c):
         self._bn_stats_off[b.name] = so
         so += self.STATS_REPLICAS * 2 * c
-      if b.attrs["relu"]:
+      if b.attrs["relu"] and b.name not in self._bn_pool:
         # written as 32-bit words: rounded up to a multiple of 4 bytes
         self._bn_mask[b.name] = self._alloc((round_up(acts[b.output].numel() // 8, 4),),
                                             torch.uint8, zero=False)
@@ -346,7 +365,19 @@ class HipExecutor:
                       mm=self._var_ptr(op.name + "/moving_mean"),
                       mv=self._var_ptr(op.name + "/moving_variance"),
                       P=P, C=C, eps=float(at["eps"]), relu=int(at["relu"]))
-        if training:
+        if training and op.name in self._bn_pool:
+          pool = self._bn_pool[op.name]
+          fused = op.name in self._bn_stats_off
+          ws = (self.bn_stats.data_ptr() + 4 * self._bn_stats_off[op.name]) if fused \
+              else self.bn_ws.data_ptr()
+          d = self._bn_pool_geometry(op, pool)
+          d.update(y=x.data_ptr(), zp=acts[pool.output].data_ptr(), gamma=common["gamma"],
+                   beta=common["beta"], mm=common["mm"], mv=common["mv"], save_mean=mean_p,
+                   save_invstd=mean_p + 4 * C, scale=mean_p + 8 * C, shift=mean_p + 12 * C, ws=ws,
+                   fused_replicas=self.STATS_REPLICAS if fused else 0, eps=float(at["eps"]),
+                   momentum=float(at["momentum"]))
+          plan.add("bn_pool_fwd_train", d, op.name + "+" + pool.name)
+        elif training:
           fused = op.name in self._bn_stats_off
           ws = (self.bn_stats.data_ptr() + 4 * self._bn_stats_off[op.name]) if fused \
               else self.bn_ws.data_ptr()
@@ -358,6 +389,8 @@ class HipExecutor:
         else:
           plan.add("bn_infer", common, op.name)
       elif op.kind == "maxpool":
+        if training and op.name in self._pool_bn:
+          continue                     # produced by the fused BatchNorm sweep above
         h, w, c = spec.shapes[op.inputs[0]]
         ho, wo, _ = spec.shapes[op.output]
         if op.name not in self._pool_idx:
@@ -378,6 +411,16 @@ class HipExecutor:
         dlogits=self.dlogits.data_ptr() if training else None, accum=self.accum.data_ptr(),
         N=N, C=spec.num_classes, ld=ld, grad_scale=1.0 / N,
         grad_scale_dev=self.loss_scale_dev.data_ptr()), "softmax_xent")
+
+  def _bn_pool_geometry(self, bn: Op, pool: Op) -> Dict:
+    """Shared descriptor fields of the fused BatchNorm + ReLU + max-pool launches."""
+    h, w, c = self.spec.shapes[pool.inputs[0]]
+    ho, wo, _ = self.spec.shapes[pool.output]
+    if pool.name not in self._pool_idx:
+      self._pool_idx[pool.name] = self._alloc((self.N, ho, wo, c), torch.uint8)
+    pa = pool.attrs
+    return dict(N=self.N, H=h, W=w, C=c, OH=ho, OW=wo, k=pa["k"], stride=pa["stride"],
+                pt=pa["pad"][0], pl=pa["pad"][2], idx=self._pool_idx[pool.name].data_ptr())
 
   def _plan_bn_fold(self, plan) -> Dict:
     """Inference: BatchNorm layers whose input comes straight from a convolution are folded into
@@ -498,10 +541,31 @@ class HipExecutor:
                   stats_y=acts[src.inputs[0]].data_ptr(),
                   stats_mask=self._bn_mask[src.name].data_ptr() if src.attrs["relu"] else None)
 
+    pooled_grad: Dict[str, torch.Tensor] = {}    # fused max-pool name -> gradient of its output
     for op in reversed(spec.ops):
       at = op.attrs
       xname = op.inputs[0]
       dout = grads.get(op.output) if op.output in written else None
+      if op.kind == "bn" and op.name in self._bn_pool:
+        # the pooled gradient is scattered back inside the BatchNorm backward sweeps
+        pool = self._bn_pool[op.name]
+        C = at["channels"]
+        mean_p = self.bn_saved.data_ptr() + 4 * self._bn_off[op.name]
+        if xname in written:
+          raise RuntimeError("BatchNorm input with several consumers is not planned")
+        d = self._bn_pool_geometry(op, pool)
+        d.update(dzp=pooled_grad.pop(pool.name).data_ptr(), y=acts[xname].data_ptr(),
+                 save_mean=mean_p, save_invstd=mean_p + 4 * C,
+                 gamma=self._var_ptr(op.name + "/gamma"),
+                 dgamma=self._var_ptr(op.name + "/gamma", "grad"),
+                 dbeta=self._var_ptr(op.name + "/beta", "grad"), dy=grad_buf(xname).data_ptr(),
+                 ws=self.bn_ws.data_ptr())
+        plan.add("bn_pool_bwd", d, op.name + "+" + pool.name + "/bwd")
+        written.add(xname)
+        done([op.name + "/gamma", op.name + "/beta"])
+        for t in op.inputs:
+          uses_left[t] = uses_left.get(t, 0) - 1
+        continue
       if dout is None and op.output in pending and op.kind != "bn":
         dout = self._materialize_pending(plan, op.output, pending, grad_buf, written)
       if dout is None and op.output not in pending:
@@ -526,6 +590,8 @@ class HipExecutor:
         plan.add("mean_bwd", dict(dy=dout.data_ptr(), dx=dx.data_ptr(), N=N,
                                   HW=at["h"] * at["w"], C=at["channels"]), op.name + "/bwd")
         written.add(xname)
+      elif op.kind == "maxpool" and op.name in self._pool_bn:
+        pooled_grad[op.name] = dout
       elif op.kind == "maxpool":
         h, w, c = spec.shapes[xname]
         ho, wo, _ = spec.shapes[op.output]

@@ -148,6 +148,31 @@ Launch make_op(const std::string& kind, const py::dict& d) {
                           fused, P, C, eps, mom, relu, s);
     };
   }
+  if (kind == "bn_pool_fwd_train" || kind == "bn_pool_bwd") {
+    const int N = get<int>(d, "N"), H = get<int>(d, "H"), W = get<int>(d, "W"), C = get<int>(d, "C");
+    const int OH = get<int>(d, "OH"), OW = get<int>(d, "OW"), k = get<int>(d, "k");
+    const int st = get<int>(d, "stride"), pt = get<int>(d, "pt"), pl = get<int>(d, "pl");
+    auto y = ptr<const bf16_t>(d, "y"); auto idx = ptr<uint8_t>(d, "idx");
+    auto gamma = ptr<const float>(d, "gamma"); auto ws = ptr<float>(d, "ws");
+    auto smean = ptr<float>(d, "save_mean"); auto sinv = ptr<float>(d, "save_invstd");
+    if (kind == "bn_pool_fwd_train") {
+      auto zp = ptr<bf16_t>(d, "zp"); auto beta = ptr<const float>(d, "beta");
+      auto mm = ptr<float>(d, "mm"); auto mv = ptr<float>(d, "mv");
+      auto scale = ptr<float>(d, "scale"); auto shift = ptr<float>(d, "shift");
+      const int fused = get_or<int>(d, "fused_replicas", 0);
+      const float eps = get<float>(d, "eps"), mom = get<float>(d, "momentum");
+      return [=](hipStream_t s) {
+        launch_bn_pool_fwd_train(y, zp, idx, gamma, beta, mm, mv, smean, sinv, scale, shift, ws,
+                                 fused, N, H, W, C, OH, OW, k, st, pt, pl, eps, mom, s);
+      };
+    }
+    auto dzp = ptr<const bf16_t>(d, "dzp"); auto dy = ptr<bf16_t>(d, "dy");
+    auto dgamma = ptr<float>(d, "dgamma"); auto dbeta = ptr<float>(d, "dbeta");
+    return [=](hipStream_t s) {
+      launch_bn_pool_bwd(dzp, idx, y, smean, sinv, gamma, dgamma, dbeta, dy, ws, N, H, W, C, OH, OW,
+                         k, st, pt, pl, s);
+    };
+  }
   if (kind == "bn_fold") {
     auto params = ptr<const float>(d, "params"); auto state = ptr<const float>(d, "state");
     auto out = ptr<float>(d, "out"); auto descs = ptr<const uint8_t>(d, "descs");

@@ -442,6 +442,161 @@ __global__ __launch_bounds__(TPB) void mask_apply_kernel(const bf16_t* __restric
   }
 }
 
+// ---- BatchNorm + ReLU feeding a max-pool (the ResNet-50 stem) --------------------------------
+// Forward: the pooled tensor is produced straight from the convolution output; the full
+// resolution activation is never written or re-read.  The winning tap is stored per pooled
+// element as in the plain max-pool (first maximum in row-major tap order); 255 means that no
+// tap was positive, i.e. the ReLU zeroed the whole window and no gradient flows.
+// Backward: the gradient of a full-resolution element is gathered from the at most
+// ceil(k/stride)^2 pooled elements whose window contains it (those it won), inside the two
+// BatchNorm backward sweeps, so the scattered gradient tensor is never materialised either.
+// Threads own a fixed 8-channel chunk (256 % (C/8) == 0), a block walks image rows.
+struct BnPoolArgs {
+  const bf16_t* y;             // [N,H,W,C] convolution output
+  bf16_t* zp;                  // [N,OH,OW,C] pooled activation (forward)
+  uint8_t* idx;                // [N,OH,OW,C] winning tap / 255
+  const bf16_t* dzp;           // [N,OH,OW,C] gradient of the pooled activation (backward)
+  bf16_t* dy;                  // [N,H,W,C] gradient of the convolution output (backward)
+  const float* scale; const float* shift;                    // forward
+  const float* mean; const float* invstd; const float* gamma;
+  const float* dgamma; const float* dbeta;                   // backward apply
+  float* ws;                                                 // backward reduce partial rows
+  int N, H, W, C, OH, OW, k, stride, pt, pl;
+};
+
+__global__ __launch_bounds__(TPB) void bn_pool_fwd_kernel(const BnPoolArgs a) {
+  const int C = a.C;
+  const uint32_t cpr = (uint32_t)C >> 3;
+  const uint32_t chunk = threadIdx.x % cpr;
+  float scale[8], shift[8];
+  load8(a.scale + chunk * 8, scale);
+  load8(a.shift + chunk * 8, shift);
+  const uint32_t per_row = (uint32_t)a.OW * cpr;
+  for (uint32_t row = blockIdx.x; row < (uint32_t)(a.N * a.OH); row += gridDim.x) {
+    const uint32_t n = row / (uint32_t)a.OH, oh = row - n * (uint32_t)a.OH;
+    for (uint32_t j = threadIdx.x; j < per_row; j += TPB) {
+      const uint32_t ow = j / cpr;
+      float best[8];
+      uint32_t bi[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { best[c] = 0.f; bi[c] = 255u; }
+      for (int kh = 0; kh < a.k; ++kh) {
+        const int hi = (int)oh * a.stride - a.pt + kh;
+        if ((unsigned)hi >= (unsigned)a.H) continue;
+        for (int kw = 0; kw < a.k; ++kw) {
+          const int wi = (int)ow * a.stride - a.pl + kw;
+          if ((unsigned)wi >= (unsigned)a.W) continue;
+          float f[8];
+          unpack8(*reinterpret_cast<const u32x4*>(
+                      a.y + ((size_t)(n * a.H + hi) * a.W + wi) * C + chunk * 8), f);
+          const uint32_t tap = (uint32_t)(kh * a.k + kw);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const float v = f[c] * scale[c] + shift[c];
+            if (v > best[c]) { best[c] = v; bi[c] = tap; }
+          }
+        }
+      }
+      const size_t o = ((size_t)row * a.OW + ow) * C + chunk * 8;
+      *reinterpret_cast<u32x4*>(a.zp + o) = pack8(best);
+      u32x2 pk;
+      pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+      pk.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+      *reinterpret_cast<u32x2*>(a.idx + o) = pk;
+    }
+  }
+}
+
+// APPLY == false: per-block partial sums of dgamma / dbeta;  true: dy.
+// Windows overlap at most two deep per dimension (stride <= k <= 2 * stride, checked on the
+// host): an input row h is tap kh0 = (h + pt) % stride of window (h + pt) / stride and tap
+// kh0 + stride of the window before it.  The four candidate windows of an element are loaded
+// unconditionally (addresses clamped) before any is used, and accumulated under predicates.
+// S: compile-time stride (0 = read it from the arguments).
+template <bool APPLY, int S>
+__global__ __launch_bounds__(TPB) void bn_pool_bwd_kernel(const BnPoolArgs a) {
+  const int C = a.C, k = a.k, stride = S ? S : a.stride;
+  const uint32_t cpr = (uint32_t)C >> 3;
+  const uint32_t chunk = threadIdx.x % cpr;
+  float mean[8], invstd[8], sc[8], c1[8], c2[8];
+  load8(a.mean + chunk * 8, mean);
+  load8(a.invstd + chunk * 8, invstd);
+  if constexpr (APPLY) {
+    const float invP = 1.f / ((float)a.N * (float)a.H * (float)a.W);
+    load8(a.gamma + chunk * 8, sc);
+    load8(a.dbeta + chunk * 8, c1);
+    load8(a.dgamma + chunk * 8, c2);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { sc[c] *= invstd[c]; c1[c] *= invP; c2[c] *= invP; }
+  }
+  float part[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) part[i] = 0.f;
+  const uint32_t per_row = (uint32_t)a.W * cpr;
+  for (uint32_t row = blockIdx.x; row < (uint32_t)(a.N * a.H); row += gridDim.x) {
+    const uint32_t n = row / (uint32_t)a.H;
+    const int h = (int)(row - n * (uint32_t)a.H);
+    const int oh0 = (h + a.pt) / stride, kh0 = (h + a.pt) - oh0 * stride;
+    // candidate window rows: {oh0, tap row kh0}, {oh0 - 1, tap row kh0 + stride}
+    const bool vh[2] = {oh0 < a.OH, kh0 + stride < k && oh0 >= 1};
+    const int ohc[2] = {oh0 < a.OH ? oh0 : a.OH - 1, oh0 >= 1 ? oh0 - 1 : 0};
+    const int khc[2] = {kh0, kh0 + stride};
+    for (uint32_t j = threadIdx.x; j < per_row; j += TPB) {
+      const int w = (int)(j / cpr);
+      const size_t off = ((size_t)row * a.W + w) * C + chunk * 8;
+      const u32x4 yq = *reinterpret_cast<const u32x4*>(a.y + off);
+      const int ow0 = (w + a.pl) / stride, kw0 = (w + a.pl) - ow0 * stride;
+      const bool vw[2] = {ow0 < a.OW, kw0 + stride < k && ow0 >= 1};
+      const int owc[2] = {ow0 < a.OW ? ow0 : a.OW - 1, ow0 >= 1 ? ow0 - 1 : 0};
+      const int kwc[2] = {kw0, kw0 + stride};
+      u32x2 pk[4];
+      u32x4 dq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const size_t o = ((size_t)(n * a.OH + ohc[q >> 1]) * a.OW + owc[q & 1]) * C + chunk * 8;
+        pk[q] = *reinterpret_cast<const u32x2*>(a.idx + o);
+        dq[q] = *reinterpret_cast<const u32x4*>(a.dzp + o);
+      }
+      float g[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) g[c] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // 0x100 never equals a stored tap: an invalid candidate contributes nothing
+        const unsigned tap = (vh[q >> 1] && vw[q & 1]) ? (unsigned)(khc[q >> 1] * k + kwc[q & 1])
+                                                       : 0x100u;
+        float d[8];
+        unpack8(dq[q], d);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const unsigned t = ((c < 4 ? pk[q].x : pk[q].y) >> (8 * (c & 3))) & 0xffu;
+          g[c] += t == tap ? d[c] : 0.f;
+        }
+      }
+      float yv[8];
+      unpack8(yq, yv);
+      if constexpr (APPLY) {
+        float o[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float xhat = (yv[c] - mean[c]) * invstd[c];
+          o[c] = sc[c] * (g[c] - c1[c] - xhat * c2[c]);
+        }
+        *reinterpret_cast<u32x4*>(a.dy + off) = pack8(o);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          part[c] += g[c] * ((yv[c] - mean[c]) * invstd[c]);
+          part[8 + c] += g[c];
+        }
+      }
+    }
+  }
+  if constexpr (!APPLY)
+    block_reduce_to_partials<16>(part, (int)cpr, (int)chunk, (int)(threadIdx.x / cpr),
+                                 a.ws + (size_t)blockIdx.x * 2 * C, C);
+}
+
 // Inference: scale = gamma / sqrt(moving_var + eps), shift = beta - moving_mean * scale for every
 // BatchNorm layer of a model in one launch (one block per layer), consumed by the folded
 // convolution epilogue.  Descriptor: five int64 element offsets (gamma and beta in `params`,
@@ -518,6 +673,70 @@ void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, uint8_t*
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, f);
   BnApplyArgs a{y, res, z, mask, scale, shift, gamma, beta, mm, mv, P, C, eps, relu};
   hipLaunchKernelGGL(bn_apply_kernel, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
+}
+
+namespace {
+void check_bn_pool(int N, int H, int W, int C, int OH, int OW, int k, int stride, int pt, int pl) {
+  check_channels(C, N * H * W);
+  if (k < 1 || k * k > 254 || stride < 1 || stride > k || k > 2 * stride || pt < 0 || pl < 0 ||
+      pt >= k || pl >= k)
+    throw std::invalid_argument("bn_pool: unsupported window (needs stride <= k <= 2 * stride)");
+  if (OH < 1 || OW < 1 || (OH - 1) * stride - pt >= H || (OW - 1) * stride - pl >= W)
+    throw std::invalid_argument("bn_pool: pooled size does not match the input");
+  if ((int64_t)N * H * W * (C / 8) >= (1ll << 31)) throw std::invalid_argument("bn_pool: tensor too large");
+}
+}  // namespace
+
+void launch_bn_pool_fwd_train(const bf16_t* y, bf16_t* zp, uint8_t* idx, const float* gamma,
+                              const float* beta, float* mm, float* mv, float* save_mean,
+                              float* save_invstd, float* scale, float* shift, float* ws,
+                              int fused_replicas, int N, int H, int W, int C, int OH, int OW, int k,
+                              int stride, int pt, int pl, float eps, float momentum, hipStream_t s) {
+  check_bn_pool(N, H, W, C, OH, OW, k, stride, pt, pl);
+  const int P = N * H * W;
+  int G = fused_replicas;
+  if (G <= 0) {
+    G = reduce_grid(P, C);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(G), dim3(TPB), 0, s, y, ws, P, C);
+  }
+  BnFinalizeArgs f{ws, G, gamma, beta, mm, mv, save_mean, save_invstd, scale, shift,
+                   P, C, eps, momentum};
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, f);
+  BnPoolArgs a{};
+  a.y = y; a.zp = zp; a.idx = idx; a.scale = scale; a.shift = shift;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.k = k; a.stride = stride;
+  a.pt = pt; a.pl = pl;
+  const int rows = N * OH;
+  hipLaunchKernelGGL(bn_pool_fwd_kernel, dim3(rows < 8192 ? rows : 8192), dim3(TPB), 0, s, a);
+}
+
+void launch_bn_pool_bwd(const bf16_t* dzp, const uint8_t* idx, const bf16_t* y, const float* mean,
+                        const float* invstd, const float* gamma, float* dgamma, float* dbeta,
+                        bf16_t* dy, float* ws, int N, int H, int W, int C, int OH, int OW, int k,
+                        int stride, int pt, int pl, hipStream_t s) {
+  check_bn_pool(N, H, W, C, OH, OW, k, stride, pt, pl);
+  BnPoolArgs a{};
+  a.y = y; a.idx = const_cast<uint8_t*>(idx); a.dzp = dzp; a.dy = dy; a.mean = mean; a.invstd = invstd; a.gamma = gamma;
+  a.dgamma = dgamma; a.dbeta = dbeta; a.ws = ws;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.k = k; a.stride = stride;
+  a.pt = pt; a.pl = pl;
+  const int rows = N * H;
+  // partial rows are 2 * C floats: a narrow layer can use many more blocks than
+  // MAX_PARTIAL_BLOCKS within the same workspace (the gathers are latency bound)
+  const int cap = (int)(bn_workspace_floats() / (2 * (size_t)C));
+  int G = rows < cap ? rows : cap;
+  if (G > 4096) G = 4096;
+  if (stride == 2)
+    hipLaunchKernelGGL((bn_pool_bwd_kernel<false, 2>), dim3(G), dim3(TPB), 0, s, a);
+  else
+    hipLaunchKernelGGL((bn_pool_bwd_kernel<false, 0>), dim3(G), dim3(TPB), 0, s, a);
+  BnBwdArgs b{nullptr, y, nullptr, nullptr, mean, invstd, gamma, dgamma, dbeta, dy, nullptr, ws, G,
+              N * H * W, C, 0};
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, b);
+  if (stride == 2)
+    hipLaunchKernelGGL((bn_pool_bwd_kernel<true, 2>), dim3(rows < 8192 ? rows : 8192), dim3(TPB), 0, s, a);
+  else
+    hipLaunchKernelGGL((bn_pool_bwd_kernel<true, 0>), dim3(rows < 8192 ? rows : 8192), dim3(TPB), 0, s, a);
 }
 
 void launch_mask_apply(const bf16_t* x, const uint8_t* mask, bf16_t* out, size_t n, hipStream_t s) {

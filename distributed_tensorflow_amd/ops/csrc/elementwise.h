@@ -15,6 +15,16 @@ void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, uint8_t*
 int bn_fold_desc_size();
 void launch_bn_fold(const float* params, const float* state, float* out, const void* descs,
                     int nlayers, hipStream_t s);
+// BatchNorm + ReLU + max-pool in one sweep (forward) and the matching backward, see bn.hip.
+void launch_bn_pool_fwd_train(const bf16_t* y, bf16_t* zp, uint8_t* idx, const float* gamma,
+                              const float* beta, float* mm, float* mv, float* save_mean,
+                              float* save_invstd, float* scale, float* shift, float* ws,
+                              int fused_replicas, int N, int H, int W, int C, int OH, int OW, int k,
+                              int stride, int pt, int pl, float eps, float momentum, hipStream_t s);
+void launch_bn_pool_bwd(const bf16_t* dzp, const uint8_t* idx, const bf16_t* y, const float* mean,
+                        const float* invstd, const float* gamma, float* dgamma, float* dbeta,
+                        bf16_t* dy, float* ws, int N, int H, int W, int C, int OH, int OW, int k,
+                        int stride, int pt, int pl, hipStream_t s);
 void launch_bn_infer(const bf16_t* y, const bf16_t* res, bf16_t* z, const float* gamma,
                      const float* beta, const float* mm, const float* mv, int P, int C, float eps,
                      int relu, hipStream_t s);

@@ -116,6 +116,39 @@ def test_folded_batchnorm_inference_matches_separate_sweeps(monkeypatch, name, b
   assert torch.allclose(outs[0][1], outs[1][1], atol=3e-2)
 
 
+def test_fused_stem_batchnorm_pool_matches_separate_launches(monkeypatch):
+  """ResNet-50's stem BatchNorm + ReLU + max-pool as one sweep each way gives the loss and
+  the gradients of the plan with separate BatchNorm and pooling launches."""
+  from distributed_tensorflow_amd.engine.hip_executor import HipExecutor
+  dev = torch.device("cuda")
+  spec = models.resnet50()
+  g = torch.Generator().manual_seed(4)
+  x = (torch.randn(8, 224, 224, 3, generator=g) * 60 + 120).to(dev)
+  y = torch.randint(0, 1001, (8,), generator=g).to(dev)
+  res = []
+  # deterministic BatchNorm statistics: otherwise the run-to-run noise of the atomically
+  # accumulated sums, amplified through 50 layers at batch 8, hides what is compared here
+  monkeypatch.setenv("DTF_BN_FUSED_STATS", "0")
+  for fuse in ("1", "0"):
+    monkeypatch.setenv("DTF_FUSE_BN_POOL", fuse)
+    st = ParamStore(spec, dev, 0)
+    ex = HipExecutor(spec, st, 8, "bf16", st.make_buckets(1), use_graph=False)
+    assert bool(ex._bn_pool) == (fuse == "1")
+    loss, _ = ex.train_step(x, y)
+    torch.cuda.synchronize()
+    res.append((loss.item(), st.grads.clone(), st.state.clone(), ex.bwd_plan.size()))
+  assert res[0][3] < res[1][3]
+  assert res[0][0] == pytest.approx(res[1][0], rel=1e-2)
+  assert torch.allclose(res[0][2], res[1][2], rtol=1e-3, atol=1e-4)       # moving statistics
+  for name in ("conv1/kernel", "bn_conv1/gamma", "bn_conv1/beta", "res2a_branch2a/kernel",
+               "fc1000/kernel"):
+    e = st.entries[name]
+    a = res[0][1][e.offset:e.offset + e.size]
+    b = res[1][1][e.offset:e.offset + e.size]
+    assert _cos(a, b) > 0.98, name
+    assert a.norm().item() == pytest.approx(b.norm().item(), rel=0.1), name
+
+
 def test_training_reduces_loss_and_graph_replay_matches_eager():
   from distributed_tensorflow_amd.engine.hip_executor import HipExecutor
   dev = torch.device("cuda")

@@ -452,6 +452,61 @@ def test_batchnorm_fwd_bwd(C, relu, residual, use_mask):
   assert torch.allclose(z2.float(), ref2, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("N,H,W,C", [(3, 12, 13, 64), (2, 9, 8, 8), (1, 16, 16, 256)])
+def test_batchnorm_relu_maxpool_fused(N, H, W, C):
+  """BatchNorm + ReLU + 3x3/2 max-pool (TensorFlow SAME) in one sweep each way against fp32
+  autograd of the same composition (reference layers `resnet_model.py:264-270`)."""
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator().manual_seed(N * 100 + C)
+  k, st = 3, 2
+  (pt, pb), (pl, pr) = same_padding(H, k, st), same_padding(W, k, st)
+  OH, OW = -(-H // st), -(-W // st)
+  P = N * H * W
+  y = _bf(torch.randn(N, H, W, C, generator=gen) * 2 + 0.3).to(dev)
+  gamma = (torch.rand(C, generator=gen) + 0.5).to(dev)
+  gamma[::3] *= -1                      # negative scales: max(bn(y)) != bn(max(y))
+  beta = (torch.randn(C, generator=gen) * 0.3).to(dev)
+  mm = torch.zeros(C, device=dev)
+  mv = torch.ones(C, device=dev)
+  saved = torch.zeros(4 * C, device=dev)
+  ws = torch.zeros(native.ext().bn_workspace_floats(), device=dev)
+  zp = torch.empty(N, OH, OW, C, dtype=torch.bfloat16, device=dev)
+  idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device=dev)
+  geo = dict(N=N, H=H, W=W, C=C, OH=OH, OW=OW, k=k, stride=st, pt=pt, pl=pl, idx=idx.data_ptr(),
+             y=y.data_ptr(), gamma=gamma.data_ptr(), ws=ws.data_ptr(),
+             save_mean=saved.data_ptr(), save_invstd=saved.data_ptr() + 4 * C)
+  native.run_op("bn_pool_fwd_train", dict(
+      zp=zp.data_ptr(), beta=beta.data_ptr(), mm=mm.data_ptr(), mv=mv.data_ptr(),
+      scale=saved.data_ptr() + 8 * C, shift=saved.data_ptr() + 12 * C, eps=1e-5, momentum=0.9,
+      **geo))
+  torch.cuda.synchronize()
+  yr = y.float().requires_grad_(True)
+  gr = gamma.clone().requires_grad_(True)
+  br = beta.clone().requires_grad_(True)
+  flat = yr.reshape(P, C)
+  mean, var = flat.mean(0), flat.var(0, unbiased=False)
+  zr = torch.relu((yr - mean) * torch.rsqrt(var + 1e-5) * gr + br)
+  pr_ = F.max_pool2d(F.pad(zr.permute(0, 3, 1, 2), (pl, pr, pt, pb), value=float("-inf")), k, st)
+  ref = pr_.permute(0, 2, 3, 1)
+  assert torch.allclose(zp.float(), ref.detach(), rtol=2e-2, atol=2e-2)
+  assert torch.allclose(mm, 0.1 * mean.detach(), rtol=1e-3, atol=1e-4)
+  assert torch.equal(idx == 255, zp == 0)            # no positive tap <=> pooled value is zero
+  dzp = _bf(torch.randn(N, OH, OW, C, generator=gen)).to(dev)
+  ref.backward(dzp.float())
+  dgamma = torch.zeros(C, device=dev)
+  dbeta = torch.zeros(C, device=dev)
+  dy = torch.full((N, H, W, C), float("nan"), dtype=torch.bfloat16, device=dev)
+  native.run_op("bn_pool_bwd", dict(dzp=dzp.data_ptr(), dy=dy.data_ptr(), dgamma=dgamma.data_ptr(),
+                                    dbeta=dbeta.data_ptr(), **geo))
+  torch.cuda.synchronize()
+  assert torch.allclose(dgamma, gr.grad, rtol=2e-2, atol=0.1)
+  assert torch.allclose(dbeta, br.grad, rtol=2e-2, atol=0.1)
+  assert torch.isfinite(dy.float()).all()
+  bad = ~torch.isclose(dy.float(), yr.grad, rtol=3e-2, atol=3e-2)
+  assert bad.float().mean().item() < 1e-3            # a near-tie may pick another tap
+
+
 def test_pooling():
   native = _native()
   dev = torch.device("cuda")
