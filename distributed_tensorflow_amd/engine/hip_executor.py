@@ -424,7 +424,7 @@ class HipExecutor:
 
   def _plan_bn_fold(self, plan) -> Dict:
     """Inference: BatchNorm layers whose input comes straight from a convolution are folded into
-    that convolution's epilogue (K6 of the kernel inventory: folded scale / shift, + ReLU, + Add;
+    that convolution's epilogue (scale / shift, + residual add, + ReLU;
     reference evaluation pass `image_classification/resnet_imagenet_main.py:256-259`).  Adds the
     launch that derives scale / shift from the current parameters and moving statistics, and
     returns {BatchNorm name: op} of the folded layers."""
