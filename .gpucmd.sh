@@ -1,5 +1,7 @@
 cd /root/repo
-timeout -k 10 600 python -u -m pytest tests/test_hip_executor.py tests/test_a_multirank_gpu.py -x -q --timeout 180 --timeout-method thread > gpurun_out/t_exec.log 2>&1 || { tail -n 40 gpurun_out/t_exec.log; exit 1; }
-tail -n 2 gpurun_out/t_exec.log
-timeout -k 10 200 python bench.py --model resnet56 --batch 128 --steps 300 --warmup 20 2>/dev/null
-timeout -k 10 200 python bench.py --model resnet56 --batch 128 --steps 300 --warmup 20 --rehearse_collectives 2>/dev/null
+timeout -k 10 600 python -u -m pytest tests/test_hip_kernels.py tests/test_hip_executor.py -x -q --timeout 180 --timeout-method thread > gpurun_out/t_fold.log 2>&1 || { tail -n 40 gpurun_out/t_fold.log; exit 1; }
+tail -n 2 gpurun_out/t_fold.log
+for f in 1 0; do
+DTF_BN_FOLD_FINALIZE=$f timeout -k 10 200 python bench.py --model resnet56 --batch 128 --steps 300 --warmup 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('r56 fold=$f', d['ms_per_step'], d['value'])"
+DTF_BN_FOLD_FINALIZE=$f timeout -k 10 200 python bench.py --steps 60 --warmup 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('r50 fold=$f', d['ms_per_step'], d['value'])"
+done

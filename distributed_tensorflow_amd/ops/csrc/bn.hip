@@ -202,13 +202,69 @@ struct BnApplyArgs {
   const float* scale; const float* shift;        // training: produced by the finalize kernel
   const float* gamma; const float* beta; const float* mm; const float* mv;   // inference
   int P, C; float eps; int relu;
+  // FOLD: the finalize step runs in the prologue of every block (see fold_columns)
+  const float* fws; int fG; float momentum;
+  float* umm; float* umv; float* save_mean; float* save_invstd; float* oscale; float* oshift;
 };
 
+// Column sums of G rows of `cols` floats (cols = 2 * C <= 512, a power of two >= 16) by one
+// block of 256 threads: float4 loads spread over (column group, row lane), one LDS round.
+// Lets a sweep over a narrow layer derive its per-channel constants itself from the few
+// replica rows the convolution epilogues filled, instead of waiting for a 5 us finalize
+// launch; a thread issues at most G * cols / 1024 loads.  Result in sums[0 .. cols).
+constexpr int FOLD_MAX_C = 256;
+__device__ __forceinline__ void fold_columns(const float* __restrict__ ws, int G, int cols,
+                                             float* part /* [1024] */, float* sums /* [512] */) {
+  const int ncg = cols >> 2, RL = TPB / ncg;
+  const int cg = threadIdx.x % ncg, rl = threadIdx.x / ncg;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int g = rl; g < G; g += RL) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)g * cols + cg * 4);
+    s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+  }
+  *reinterpret_cast<f32x4*>(part + rl * cols + cg * 4) = s;
+  __syncthreads();
+  for (int col = threadIdx.x; col < cols; col += TPB) {
+    float t = 0.f;
+    for (int r = 0; r < RL; ++r) t += part[r * cols + col];
+    sums[col] = t;
+  }
+  __syncthreads();
+}
+
+template <bool FOLD>
 __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
   const int C = a.C, tpr = C >> 3, rpb = TPB / tpr;
   const int chunk = threadIdx.x % tpr, rowid = threadIdx.x / tpr;
   float scale[8], shift[8];
-  if (a.scale) {
+  if constexpr (FOLD) {
+    __shared__ __attribute__((aligned(16))) float part[1024];
+    __shared__ __attribute__((aligned(16))) float sums[2 * FOLD_MAX_C];
+    fold_columns(a.fws, a.fG, 2 * C, part, sums);
+    float* sc = part;                // reuse: [C] scale, [C] shift
+    float* sh = part + FOLD_MAX_C;
+    for (int ch = threadIdx.x; ch < C; ch += TPB) {
+      const float invP = 1.f / (float)a.P;
+      const float mean = sums[ch] * invP;
+      const float var = fmaxf(sums[C + ch] * invP - mean * mean, 0.f);
+      const float invstd = rsqrtf(var + a.eps);
+      const float k = a.gamma[ch] * invstd;
+      sc[ch] = k;
+      sh[ch] = a.beta[ch] - mean * k;
+      if (blockIdx.x == 0) {         // one block publishes what backward / inference need
+        a.oscale[ch] = k;
+        a.oshift[ch] = sh[ch];
+        a.save_mean[ch] = mean;
+        a.save_invstd[ch] = invstd;
+        const float unbiased = a.P > 1 ? var * ((float)a.P / (float)(a.P - 1)) : var;
+        a.umm[ch] = a.umm[ch] * a.momentum + mean * (1.f - a.momentum);
+        a.umv[ch] = a.umv[ch] * a.momentum + unbiased * (1.f - a.momentum);
+      }
+    }
+    __syncthreads();
+    load8(sc + chunk * 8, scale);
+    load8(sh + chunk * 8, shift);
+  } else if (a.scale) {
     load8(a.scale + chunk * 8, scale);
     load8(a.shift + chunk * 8, shift);
   } else {
@@ -668,11 +724,20 @@ void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, uint8_t*
     G = reduce_grid(P, C);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(G), dim3(TPB), 0, s, y, ws, P, C);
   }
+  static const bool fold_ok = [] {
+    const char* e = std::getenv("DTF_BN_FOLD_FINALIZE");
+    return !(e && e[0] == '0');
+  }();
+  BnApplyArgs a{y, res, z, mask, scale, shift, gamma, beta, mm, mv, P, C, eps, relu,
+                ws, G, momentum, mm, mv, save_mean, save_invstd, scale, shift};
+  if (fold_ok && fused_replicas > 0 && fused_replicas * 2 * C <= 16384 && C <= FOLD_MAX_C) {
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
+    return;
+  }
   BnFinalizeArgs f{ws, G, gamma, beta, mm, mv, save_mean, save_invstd, scale, shift,
                    P, C, eps, momentum};
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, f);
-  BnApplyArgs a{y, res, z, mask, scale, shift, gamma, beta, mm, mv, P, C, eps, relu};
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
+  hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
 }
 
 namespace {
@@ -752,8 +817,9 @@ void launch_bn_infer(const bf16_t* y, const bf16_t* res, bf16_t* z, const float*
                      const float* beta, const float* mm, const float* mv, int P, int C, float eps,
                      int relu, hipStream_t s) {
   check_channels(C, P);
-  BnApplyArgs a{y, res, z, nullptr, nullptr, nullptr, gamma, beta, mm, mv, P, C, eps, relu};
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
+  BnApplyArgs a{y, res, z, nullptr, nullptr, nullptr, gamma, beta, mm, mv, P, C, eps, relu,
+                nullptr, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
 }
 
 void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const uint8_t* mask,

@@ -145,6 +145,13 @@ def test_conv_fused_bn_statistics(case):
     torch.cuda.synchronize()
     ref = (o - o.mean(0)) * torch.rsqrt(o.var(0, unbiased=False) + 1e-5)
     assert torch.allclose(z.float(), ref, rtol=2e-2, atol=2e-2)
+    # what the finalize step (a launch of its own, or the prologue of the sweep on narrow
+    # layers) leaves for backward and for inference
+    assert torch.allclose(saved[:Cout], o.mean(0), rtol=1e-3, atol=1e-3)
+    assert torch.allclose(saved[Cout:2 * Cout], torch.rsqrt(o.var(0, unbiased=False) + 1e-5),
+                          rtol=2e-3, atol=1e-3)
+    assert torch.allclose(mm, 0.1 * o.mean(0), rtol=1e-3, atol=1e-4)
+    assert torch.allclose(mv, 0.9 + 0.1 * o.var(0, unbiased=True), rtol=2e-3, atol=1e-4)
 
 
 @pytest.mark.parametrize("case", [
