@@ -418,6 +418,10 @@ __global__ __launch_bounds__(FIN_TPB) void bn_bwd_finalize_kernel(const BnBwdArg
   }
 }
 
+// FOLD: `ws` holds G replica rows of [sum g | sum g*y] (left by the data-gradient epilogues) of
+// a narrow layer; every block derives dbeta / dgamma itself (block 0 stores them into the
+// gradient buffer) instead of waiting for a finalize launch.
+template <bool FOLD>
 __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   const int C = a.C, tpr = C >> 3, rpb = TPB / tpr;
   const int chunk = threadIdx.x % tpr, rowid = threadIdx.x / tpr;
@@ -426,8 +430,29 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   load8(a.mean + chunk * 8, mean);
   load8(a.invstd + chunk * 8, invstd);
   load8(a.gamma + chunk * 8, scale);
-  load8(a.dbeta + chunk * 8, c1);
-  load8(a.dgamma + chunk * 8, c2);
+  if constexpr (FOLD) {
+    __shared__ __attribute__((aligned(16))) float part[1024];
+    __shared__ __attribute__((aligned(16))) float sums[2 * FOLD_MAX_C];
+    fold_columns(a.ws, a.G, 2 * C, part, sums);
+    float* db = part;                // reuse: [C] dbeta, [C] dgamma
+    float* dg = part + FOLD_MAX_C;
+    for (int ch = threadIdx.x; ch < C; ch += TPB) {
+      const float sg = sums[ch], sgy = sums[C + ch];
+      const float g2 = (sgy - a.mean[ch] * sg) * a.invstd[ch];
+      db[ch] = sg;
+      dg[ch] = g2;
+      if (blockIdx.x == 0) {
+        a.dbeta[ch] = sg;
+        a.dgamma[ch] = g2;
+      }
+    }
+    __syncthreads();
+    load8(db + chunk * 8, c1);
+    load8(dg + chunk * 8, c2);
+  } else {
+    load8(a.dbeta + chunk * 8, c1);
+    load8(a.dgamma + chunk * 8, c2);
+  }
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     scale[c] *= invstd[c];
@@ -831,8 +856,16 @@ void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const uin
   const int G = pre_replicas > 0 ? pre_replicas : reduce_grid(P, C);
   BnBwdArgs a{dz, y, z, mask, mean, invstd, gamma, dgamma, dbeta, dy, dres, ws, G, P, C,
               pre_replicas > 0 ? 1 : 0};
+  static const bool fold_ok = [] {
+    const char* e = std::getenv("DTF_BN_FOLD_FINALIZE");
+    return !(e && e[0] == '0');
+  }();
+  if (fold_ok && pre_replicas > 0 && pre_replicas * 2 * C <= 16384 && C <= FOLD_MAX_C) {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
+    return;
+  }
   if (pre_replicas == 0)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(G), dim3(TPB), 0, s, a);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, a);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
 }
