@@ -1,7 +1,4 @@
 cd /root/repo
-timeout -k 10 600 python -u -m pytest tests/test_hip_kernels.py tests/test_hip_executor.py -x -q --timeout 180 --timeout-method thread > gpurun_out/t_fold.log 2>&1 || { tail -n 40 gpurun_out/t_fold.log; exit 1; }
-tail -n 2 gpurun_out/t_fold.log
-for f in 1 0; do
-DTF_BN_FOLD_FINALIZE=$f timeout -k 10 200 python bench.py --model resnet56 --batch 128 --steps 300 --warmup 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('r56 fold=$f', d['ms_per_step'], d['value'])"
-DTF_BN_FOLD_FINALIZE=$f timeout -k 10 200 python bench.py --steps 60 --warmup 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('r50 fold=$f', d['ms_per_step'], d['value'])"
-done
+export TMPDIR=/tmp
+DTF_WGRAD_STREAM=0 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof56 -- python bench.py --model resnet56 --batch 128 --steps 20 --warmup 2 --no_graph > gpurun_out/prof56.log 2>&1 || { tail -n 30 gpurun_out/prof56.log; exit 1; }
+python scripts/summarize_profile.py stats gpurun_out/prof56 30
