@@ -1,4 +1,6 @@
 cd /root/repo
-export TMPDIR=/tmp
-DTF_WGRAD_STREAM=0 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof56 -- python bench.py --model resnet56 --batch 128 --steps 20 --warmup 2 --no_graph > gpurun_out/prof56.log 2>&1 || { tail -n 30 gpurun_out/prof56.log; exit 1; }
-python scripts/summarize_profile.py stats gpurun_out/prof56 30
+timeout -k 10 600 python -u -m pytest tests/test_hip_executor.py -x -q --timeout 180 --timeout-method thread > gpurun_out/t_defer.log 2>&1 || { tail -n 40 gpurun_out/t_defer.log; exit 1; }
+tail -n 2 gpurun_out/t_defer.log
+for f in 1 0 1 0; do
+DTF_DEFER_STRIDED_DGRAD=$f timeout -k 10 200 python bench.py --steps 60 --warmup 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('r50 defer=$f', d['ms_per_step'], d['value'])"
+done

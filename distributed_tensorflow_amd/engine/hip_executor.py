@@ -565,6 +565,8 @@ class HipExecutor:
                   stats_mask=self._bn_mask[src.name].data_ptr() if src.attrs["relu"] else None)
 
     pooled_grad: Dict[str, torch.Tensor] = {}    # fused max-pool name -> gradient of its output
+    deferred: Dict[str, List] = {}               # tensor -> strided data gradients waiting for
+    defer_ok = os.environ.get("DTF_DEFER_STRIDED_DGRAD", "1") != "0"    # its first writer
     for op in reversed(spec.ops):
       at = op.attrs
       xname = op.inputs[0]
@@ -663,7 +665,17 @@ class HipExecutor:
         self._add_wgrad(plan, g.wgrad(acts[xname].data_ptr(), dout.data_ptr(),
                                       self._var_ptr(op.name + "/kernel", "grad")),
                         op.name + "/wgrad")
-        if op is not first_conv:
+        if (op is not first_conv and g.has_empty_parities() and defer_ok
+            and uses_left.get(xname, 0) > 1 and xname not in written and xname not in pending
+            and acts[xname].numel() * 2 > small):
+          # A strided projection shortcut reaches one output parity in four.  As the first
+          # writer of the block input's gradient it would fill the other three with zeros,
+          # which the main branch's data gradient then reads back to accumulate; deferred
+          # until that gradient has been written, it only accumulates into its own parity.
+          # (Small tensors keep the order: their final writer also accumulates the
+          # BatchNorm backward statistics and must cover every pixel.)
+          deferred.setdefault(xname, []).append((op, g, dout))
+        elif op is not first_conv:
           dx = grad_buf(xname)
           add, add_mask = None, None
           if xname in pending and xname not in written and g.Cin % 8 == 0:
@@ -677,9 +689,15 @@ class HipExecutor:
             d.update(extra)
             self._add(plan, "conv", d, op.name + "/dgrad")
           written.add(xname)
+          for op2, g2, dout2 in deferred.pop(xname, []):
+            for d in g2.dgrad(dout2.data_ptr(), self._wd_ptr(op2.name), dx.data_ptr(),
+                              accumulate=True, skip_empty=True):
+              self._add(plan, "conv", d, op2.name + "/dgrad")
         done([op.name + "/kernel"])
       for t in op.inputs:
         uses_left[t] = uses_left.get(t, 0) - 1
+    if deferred:
+      raise RuntimeError("deferred data gradients never issued: %s" % sorted(deferred))
     self._flush_wgrads(plan)
     if self.overlap_wgrad:
       plan.add("join", {}, "join")               # the step ends with the side lane collected

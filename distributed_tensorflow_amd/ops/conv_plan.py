@@ -173,9 +173,13 @@ class ConvGeom:
   # -- data gradient ------------------------------------------------------------------------
   def dgrad(self, dy: int, wd: int, dx: int, accumulate: bool = False,
             cfg: Optional[int] = None, addend: Optional[int] = None,
-            addend_mask: Optional[int] = None) -> List[Dict]:
+            addend_mask: Optional[int] = None, skip_empty: bool = False) -> List[Dict]:
     """dX[N,H,W,Cin] from dY[N,OH,OW,ldc]; `accumulate` adds to the existing dX, `addend`
-    (a tensor shaped like dX, optionally gated by the 1-bit `addend_mask`) is added instead."""
+    (a tensor shaped like dX, optionally gated by the 1-bit `addend_mask`) is added instead.
+
+    A strided convolution is one launch per output parity; parities no tap reaches (three of
+    the four of a 1x1 / stride 2 projection) only write zeros or the addend.  With
+    `accumulate` they would rewrite dX unchanged: `skip_empty` leaves them out."""
     if accumulate and addend is not None:
       raise ValueError("either accumulate into dX or add another tensor")
     if self.mode != "normal" or self.Cin % 8:
@@ -199,6 +203,8 @@ class ConvGeom:
         owg = -(-(self.W - pw) // s)
         if owg <= 0:
           continue
+        if skip_empty and accumulate and ti * tj == 0:
+          continue
         M = self.N * ohg * owg
         d = dict(N=self.N, H=self.OH, W=self.OW, Cpix=ct, OH=ohg, OW=owg,
                  OHfull=self.H, OWfull=self.W, Cout=self.Cin, ldc=self.Cin,
@@ -214,6 +220,10 @@ class ConvGeom:
           d["addend_mask"] = addend_mask
         out.append(d)
     return out
+
+  def has_empty_parities(self) -> bool:
+    """True when some output parity of the data gradient is reached by no tap."""
+    return self.stride > self.KH or self.stride > self.KW
 
   # -- weight gradient ------------------------------------------------------------------------
   def wgrad(self, x: int, dy: int, dw: int, cfg: Optional[int] = None,

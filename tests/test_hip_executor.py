@@ -149,6 +149,37 @@ def test_fused_stem_batchnorm_pool_matches_separate_launches(monkeypatch):
     assert a.norm().item() == pytest.approx(b.norm().item(), rel=0.1), name
 
 
+def test_deferred_projection_data_gradient_matches_plain_order(monkeypatch):
+  """The strided 1x1 projection's data gradient issued after the main branch's (accumulating
+  into its one live output parity only) gives the gradients of the plan in which it is the
+  first writer and fills the other parities with zeros."""
+  from distributed_tensorflow_amd.engine.hip_executor import HipExecutor
+  dev = torch.device("cuda")
+  spec = models.resnet50()
+  g = torch.Generator().manual_seed(5)
+  x = (torch.randn(8, 224, 224, 3, generator=g) * 60 + 120).to(dev)
+  y = torch.randint(0, 1001, (8,), generator=g).to(dev)
+  monkeypatch.setenv("DTF_BN_FUSED_STATS", "0")            # deterministic forward
+  monkeypatch.setenv("DTF_BWD_STATS_SMALL_BYTES", "0")     # every tensor counts as large
+  res = []
+  for defer in ("1", "0"):
+    monkeypatch.setenv("DTF_DEFER_STRIDED_DGRAD", defer)
+    st = ParamStore(spec, dev, 0)
+    ex = HipExecutor(spec, st, 8, "bf16", st.make_buckets(1), use_graph=False)
+    loss, _ = ex.train_step(x, y)
+    torch.cuda.synchronize()
+    res.append((loss.item(), st.grads.clone(), ex.bwd_plan.size()))
+  assert res[0][2] == res[1][2] - 9                 # three projections x three empty parities
+  assert res[0][0] == pytest.approx(res[1][0], rel=1e-5)
+  for name in ("conv1/kernel", "res2c_branch2c/kernel", "res3a_branch1/kernel",
+               "res3d_branch2a/kernel", "res4a_branch2a/kernel", "bn2c_branch2c/gamma"):
+    e = st.entries[name]
+    a = res[0][1][e.offset:e.offset + e.size]
+    b = res[1][1][e.offset:e.offset + e.size]
+    assert _cos(a, b) > 0.995, name
+    assert a.norm().item() == pytest.approx(b.norm().item(), rel=3e-2), name
+
+
 def test_training_reduces_loss_and_graph_replay_matches_eager():
   from distributed_tensorflow_amd.engine.hip_executor import HipExecutor
   dev = torch.device("cuda")
