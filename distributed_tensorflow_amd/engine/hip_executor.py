@@ -565,12 +565,18 @@ class HipExecutor:
                   stats_mask=self._bn_mask[src.name].data_ptr() if src.attrs["relu"] else None)
 
     pooled_grad: Dict[str, torch.Tensor] = {}    # fused max-pool name -> gradient of its output
+    dual_done: set = set()                       # BatchNorms whose backward ran in a dual launch
+    self.bn_ws2 = None
     deferred: Dict[str, List] = {}               # tensor -> strided data gradients waiting for
     defer_ok = os.environ.get("DTF_DEFER_STRIDED_DGRAD", "1") != "0"    # its first writer
     for op in reversed(spec.ops):
       at = op.attrs
       xname = op.inputs[0]
       dout = grads.get(op.output) if op.output in written else None
+      if op.kind == "bn" and op.name in dual_done:
+        for t in op.inputs:              # its backward ran together with the block's last layer
+          uses_left[t] = uses_left.get(t, 0) - 1
+        continue
       if op.kind == "bn" and op.name in self._bn_pool:
         # the pooled gradient is scattered back inside the BatchNorm backward sweeps
         pool = self._bn_pool[op.name]
@@ -639,6 +645,34 @@ class HipExecutor:
           raise RuntimeError("BatchNorm input with several consumers is not planned")
         dy = grad_buf(xname)
         dz_ptr, mask_ptr = self._bn_incoming_grad(plan, op, dout, pending)
+        partner = self._dual_bwd_partner(op, dout, mask_ptr, producer, consumers, written, pending)
+        if partner is not None:
+          # this block's projection-shortcut BatchNorm receives the same masked gradient: one
+          # pair of sweeps reads dz and the mask once for both layers
+          C2 = partner.attrs["channels"]
+          x2 = partner.inputs[0]
+          m2 = self.bn_saved.data_ptr() + 4 * self._bn_off[partner.name]
+          if self.bn_ws2 is None:
+            self.bn_ws2 = self._alloc((native.ext().bn_workspace_floats(),), torch.float32)
+          plan.add("bn_bwd_dual", dict(
+              dz=dz_ptr, mask=mask_ptr, P=P, C=C, ws=self.bn_ws.data_ptr(),
+              ws2=self.bn_ws2.data_ptr(),
+              y=x.data_ptr(), mean=mean_p, invstd=inv_p, gamma=self._var_ptr(op.name + "/gamma"),
+              dgamma=self._var_ptr(op.name + "/gamma", "grad"),
+              dbeta=self._var_ptr(op.name + "/beta", "grad"), dy=dy.data_ptr(),
+              y2=acts[x2].data_ptr(), mean2=m2, invstd2=m2 + 4 * C2,
+              gamma2=self._var_ptr(partner.name + "/gamma"),
+              dgamma2=self._var_ptr(partner.name + "/gamma", "grad"),
+              dbeta2=self._var_ptr(partner.name + "/beta", "grad"),
+              dy2=grad_buf(x2).data_ptr()), op.name + "+" + partner.name + "/bwd")
+          written.add(xname)
+          written.add(x2)
+          dual_done.add(partner.name)
+          done([op.name + "/gamma", op.name + "/beta", partner.name + "/gamma",
+                partner.name + "/beta"])
+          for t in op.inputs:
+            uses_left[t] = uses_left.get(t, 0) - 1
+          continue
         if len(op.inputs) > 1:
           # The gradient of the residual branch is dz gated by this layer's ReLU mask.  It is
           # not written out: whoever consumes it (the data gradient of the block's first
@@ -706,6 +740,26 @@ class HipExecutor:
     left = [i for i, r in remaining.items() if r]
     if left:
       raise RuntimeError("buckets never completed: %s" % left)
+
+  def _dual_bwd_partner(self, op: Op, dout, mask_ptr, producer, consumers, written,
+                        pending) -> Optional[Op]:
+    """The BatchNorm of the projection shortcut that feeds `op` as its residual, when the two
+    backward passes can share their sweeps: same shape, the partner has no ReLU and no
+    residual of its own, its output is consumed by `op` only, and neither layer's reductions
+    were already accumulated by a data-gradient epilogue."""
+    if os.environ.get("DTF_BN_DUAL_BWD", "1") == "0":
+      return None
+    if len(op.inputs) < 2 or dout is None or mask_ptr is None or op.name in self._bn_pre_stats:
+      return None
+    rname = op.inputs[1]
+    p = producer.get(rname)
+    if (p is None or p.kind != "bn" or p.attrs["relu"] or len(p.inputs) != 1
+        or consumers.get(rname, 0) != 1 or rname in written or rname in pending
+        or p.attrs["channels"] != op.attrs["channels"] or p.name in self._bn_pool
+        or p.inputs[0] in written
+        or tuple(self.acts[p.inputs[0]].shape) != tuple(self.acts[op.inputs[0]].shape)):
+      return None
+    return p
 
   def _materialize_pending(self, plan, name: str, pending, grad_buf, written) -> torch.Tensor:
     """Writes a deferred `dz * mask` gradient into the gradient buffer of `name`."""

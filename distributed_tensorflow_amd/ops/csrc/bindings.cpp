@@ -206,6 +206,22 @@ Launch make_op(const std::string& kind, const py::dict& d) {
       launch_bn_bwd(dz, y, z, mask, mean, inv, gamma, dgamma, dbeta, dy, dres, ws, P, C, pre, s);
     };
   }
+  if (kind == "bn_bwd_dual") {
+    auto dz = ptr<const bf16_t>(d, "dz"); auto mask = ptr<const uint8_t>(d, "mask");
+    auto ws = ptr<float>(d, "ws"); auto ws2 = ptr<float>(d, "ws2");
+    const int P = get<int>(d, "P"), C = get<int>(d, "C");
+    auto y1 = ptr<const bf16_t>(d, "y"); auto y2 = ptr<const bf16_t>(d, "y2");
+    auto m1 = ptr<const float>(d, "mean"); auto m2 = ptr<const float>(d, "mean2");
+    auto i1 = ptr<const float>(d, "invstd"); auto i2 = ptr<const float>(d, "invstd2");
+    auto g1 = ptr<const float>(d, "gamma"); auto g2 = ptr<const float>(d, "gamma2");
+    auto dg1 = ptr<float>(d, "dgamma"); auto dg2 = ptr<float>(d, "dgamma2");
+    auto db1 = ptr<float>(d, "dbeta"); auto db2 = ptr<float>(d, "dbeta2");
+    auto dy1 = ptr<bf16_t>(d, "dy"); auto dy2 = ptr<bf16_t>(d, "dy2");
+    return [=](hipStream_t s) {
+      launch_bn_bwd_dual(dz, mask, P, C, ws, ws2, y1, m1, i1, g1, dg1, db1, dy1, y2, m2, i2, g2, dg2,
+                         db2, dy2, s);
+    };
+  }
   if (kind == "mask_apply") {
     auto x = ptr<const bf16_t>(d, "x"); auto mask = ptr<const uint8_t>(d, "mask");
     auto out = ptr<bf16_t>(d, "out");

@@ -344,19 +344,32 @@ struct BnBwdArgs {
   int P, C;
   int raw;                  // 1: `ws` rows hold [sum g | sum g*y] (from the data-gradient
                             // epilogues) instead of [dgamma | dbeta]
+  // Second BatchNorm fed by the same gradient (NB == 2 instantiations): the projection
+  // shortcut's layer next to the block's last one.  Both see g = dz gated by the mask, so one
+  // sweep reads dz and the mask once for the two of them.  No ReLU of its own, no dres.
+  const bf16_t* y2; const float* mean2; const float* invstd2; const float* gamma2;
+  float* dgamma2; float* dbeta2; bf16_t* dy2; float* ws2;
 };
 
+template <int NB>
 __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
   const int C = a.C, tpr = C >> 3, rpb = TPB / tpr;
   const int chunk = threadIdx.x % tpr, rowid = threadIdx.x / tpr;
-  float mean[8], invstd[8];
+  float mean[8], invstd[8], mean2[8], invstd2[8];
   load8(a.mean + chunk * 8, mean);
   load8(a.invstd + chunk * 8, invstd);
-  float part[16];
+  if constexpr (NB == 2) {
+    load8(a.mean2 + chunk * 8, mean2);
+    load8(a.invstd2 + chunk * 8, invstd2);
+  }
+  float part[16], part2[8];          // [dgamma | dbeta], dgamma of the second layer
 #pragma unroll
   for (int i = 0; i < 16; ++i) part[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) part2[i] = 0.f;
   const int mode = a.mask ? 2 : (a.z ? 1 : 0);
-  auto accumulate = [&](const u32x4& gv, const u32x4& yq, const u32x4& zq, uint32_t bits) {
+  auto accumulate = [&](const u32x4& gv, const u32x4& yq, const u32x4& zq, uint32_t bits,
+                        const u32x4& y2q) {
     float g[8], yv[8];
     unpack8(gv, g);
     unpack8(yq, yv);
@@ -374,11 +387,17 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
       part[c] += g[c] * ((yv[c] - mean[c]) * invstd[c]);   // dgamma
       part[8 + c] += g[c];                                  // dbeta
     }
+    if constexpr (NB == 2) {
+      float y2v[8];
+      unpack8(y2q, y2v);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) part2[c] += g[c] * ((y2v[c] - mean2[c]) * invstd2[c]);
+    }
   };
   const int stride = gridDim.x * rpb;
   int row = blockIdx.x * rpb + rowid;
   for (; row + 3 * stride < a.P; row += 4 * stride) {      // four rows of loads in flight
-    u32x4 gv[4], yq[4], zq[4];
+    u32x4 gv[4], yq[4], zq[4], y2q[4];
     uint32_t bits[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -387,9 +406,10 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
       yq[u] = *reinterpret_cast<const u32x4*>(a.y + off);
       zq[u] = mode == 1 ? *reinterpret_cast<const u32x4*>(a.z + off) : u32x4{0, 0, 0, 0};
       bits[u] = mode == 2 ? a.mask[(size_t)(row + u * stride) * tpr + chunk] : 0u;
+      y2q[u] = NB == 2 ? *reinterpret_cast<const u32x4*>(a.y2 + off) : u32x4{0, 0, 0, 0};
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) accumulate(gv[u], yq[u], zq[u], bits[u]);
+    for (int u = 0; u < 4; ++u) accumulate(gv[u], yq[u], zq[u], bits[u], y2q[u]);
   }
   for (; row < a.P; row += stride) {
     const size_t off = (size_t)row * C + chunk * 8;
@@ -397,9 +417,19 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
     const u32x4 yq = *reinterpret_cast<const u32x4*>(a.y + off);
     const u32x4 zq = mode == 1 ? *reinterpret_cast<const u32x4*>(a.z + off) : u32x4{0, 0, 0, 0};
     const uint32_t bits = mode == 2 ? a.mask[(size_t)row * tpr + chunk] : 0u;
-    accumulate(gv, yq, zq, bits);
+    const u32x4 y2q = NB == 2 ? *reinterpret_cast<const u32x4*>(a.y2 + off) : u32x4{0, 0, 0, 0};
+    accumulate(gv, yq, zq, bits, y2q);
   }
-  block_reduce_to_partials<16>(part, tpr, chunk, rowid, a.ws + (size_t)blockIdx.x * 2 * C, C);
+  if constexpr (NB == 2) {
+    float second[16];                // [dgamma2 | dbeta] (same g: same dbeta), copied before the
+#pragma unroll                       // first reduction overwrites `part` in the writing threads
+    for (int c = 0; c < 8; ++c) { second[c] = part2[c]; second[8 + c] = part[8 + c]; }
+    block_reduce_to_partials<16>(part, tpr, chunk, rowid, a.ws + (size_t)blockIdx.x * 2 * C, C);
+    __syncthreads();                 // the LDS scratch of the reduction is reused
+    block_reduce_to_partials<16>(second, tpr, chunk, rowid, a.ws2 + (size_t)blockIdx.x * 2 * C, C);
+  } else {
+    block_reduce_to_partials<16>(part, tpr, chunk, rowid, a.ws + (size_t)blockIdx.x * 2 * C, C);
+  }
 }
 
 __global__ __launch_bounds__(FIN_TPB) void bn_bwd_finalize_kernel(const BnBwdArgs a) {
@@ -421,7 +451,7 @@ __global__ __launch_bounds__(FIN_TPB) void bn_bwd_finalize_kernel(const BnBwdArg
 // FOLD: `ws` holds G replica rows of [sum g | sum g*y] (left by the data-gradient epilogues) of
 // a narrow layer; every block derives dbeta / dgamma itself (block 0 stores them into the
 // gradient buffer) instead of waiting for a finalize launch.
-template <bool FOLD>
+template <bool FOLD, int NB = 1>
 __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   const int C = a.C, tpr = C >> 3, rpb = TPB / tpr;
   const int chunk = threadIdx.x % tpr, rowid = threadIdx.x / tpr;
@@ -459,8 +489,23 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
     c1[c] *= invP;
     c2[c] *= invP;
   }
+  float mean2[8], invstd2[8], scale2[8], c12[8], c22[8];
+  if constexpr (NB == 2) {
+    load8(a.mean2 + chunk * 8, mean2);
+    load8(a.invstd2 + chunk * 8, invstd2);
+    load8(a.gamma2 + chunk * 8, scale2);
+    load8(a.dbeta2 + chunk * 8, c12);
+    load8(a.dgamma2 + chunk * 8, c22);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      scale2[c] *= invstd2[c];
+      c12[c] *= invP;
+      c22[c] *= invP;
+    }
+  }
   const int mode = a.mask ? 2 : (a.z ? 1 : 0);
-  auto finish = [&](const u32x4& gv, const u32x4& yq, const u32x4& zq, uint32_t bits, size_t off) {
+  auto finish = [&](const u32x4& gv, const u32x4& yq, const u32x4& zq, uint32_t bits, size_t off,
+                    const u32x4& y2q) {
     float g[8], yv[8];
     unpack8(gv, g);
     unpack8(yq, yv);
@@ -481,11 +526,21 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
       o[c] = scale[c] * (g[c] - c1[c] - xhat * c2[c]);
     }
     *reinterpret_cast<u32x4*>(a.dy + off) = pack8(o);
+    if constexpr (NB == 2) {
+      float y2v[8], o2[8];
+      unpack8(y2q, y2v);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float xhat = (y2v[c] - mean2[c]) * invstd2[c];
+        o2[c] = scale2[c] * (g[c] - c12[c] - xhat * c22[c]);
+      }
+      *reinterpret_cast<u32x4*>(a.dy2 + off) = pack8(o2);
+    }
   };
   const int stride = gridDim.x * rpb;
   int row = blockIdx.x * rpb + rowid;
   for (; row + 3 * stride < a.P; row += 4 * stride) {      // four rows of loads in flight
-    u32x4 gv[4], yq[4], zq[4];
+    u32x4 gv[4], yq[4], zq[4], y2q[4];
     uint32_t bits[4];
     size_t off[4];
 #pragma unroll
@@ -495,9 +550,10 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
       yq[u] = *reinterpret_cast<const u32x4*>(a.y + off[u]);
       zq[u] = mode == 1 ? *reinterpret_cast<const u32x4*>(a.z + off[u]) : u32x4{0, 0, 0, 0};
       bits[u] = mode == 2 ? a.mask[(size_t)(row + u * stride) * tpr + chunk] : 0u;
+      y2q[u] = NB == 2 ? *reinterpret_cast<const u32x4*>(a.y2 + off[u]) : u32x4{0, 0, 0, 0};
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) finish(gv[u], yq[u], zq[u], bits[u], off[u]);
+    for (int u = 0; u < 4; ++u) finish(gv[u], yq[u], zq[u], bits[u], off[u], y2q[u]);
   }
   for (; row < a.P; row += stride) {
     const size_t off = (size_t)row * C + chunk * 8;
@@ -505,7 +561,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
     const u32x4 yq = *reinterpret_cast<const u32x4*>(a.y + off);
     const u32x4 zq = mode == 1 ? *reinterpret_cast<const u32x4*>(a.z + off) : u32x4{0, 0, 0, 0};
     const uint32_t bits = mode == 2 ? a.mask[(size_t)row * tpr + chunk] : 0u;
-    finish(gv, yq, zq, bits, off);
+    const u32x4 y2q = NB == 2 ? *reinterpret_cast<const u32x4*>(a.y2 + off) : u32x4{0, 0, 0, 0};
+    finish(gv, yq, zq, bits, off, y2q);
   }
 }
 
@@ -821,7 +878,7 @@ void launch_bn_pool_bwd(const bf16_t* dzp, const uint8_t* idx, const bf16_t* y, 
   else
     hipLaunchKernelGGL((bn_pool_bwd_kernel<false, 0>), dim3(G), dim3(TPB), 0, s, a);
   BnBwdArgs b{nullptr, y, nullptr, nullptr, mean, invstd, gamma, dgamma, dbeta, dy, nullptr, ws, G,
-              N * H * W, C, 0};
+              N * H * W, C, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, b);
   if (stride == 2)
     hipLaunchKernelGGL((bn_pool_bwd_kernel<true, 2>), dim3(rows < 8192 ? rows : 8192), dim3(TPB), 0, s, a);
@@ -855,7 +912,8 @@ void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const uin
   if (pre_replicas < 0) throw std::invalid_argument("bn_bwd: negative replica count");
   const int G = pre_replicas > 0 ? pre_replicas : reduce_grid(P, C);
   BnBwdArgs a{dz, y, z, mask, mean, invstd, gamma, dgamma, dbeta, dy, dres, ws, G, P, C,
-              pre_replicas > 0 ? 1 : 0};
+              pre_replicas > 0 ? 1 : 0,
+              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   static const bool fold_ok = [] {
     const char* e = std::getenv("DTF_BN_FOLD_FINALIZE");
     return !(e && e[0] == '0');
@@ -865,7 +923,29 @@ void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const uin
     return;
   }
   if (pre_replicas == 0)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(G), dim3(TPB), 0, s, a);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(G), dim3(TPB), 0, s, a);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, a);
   hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
+}
+
+// Backward of two BatchNorm layers that receive the same gradient g = dz gated by `mask`
+// (a block's last BatchNorm and the one of its projection shortcut): dz and the mask are
+// read once per sweep for both.  `ws` / `ws2`: a partial-sum workspace per layer.
+void launch_bn_bwd_dual(const bf16_t* dz, const uint8_t* mask, int P, int C, float* ws, float* ws2,
+                        const bf16_t* y1, const float* mean1, const float* invstd1,
+                        const float* gamma1, float* dgamma1, float* dbeta1, bf16_t* dy1,
+                        const bf16_t* y2, const float* mean2, const float* invstd2,
+                        const float* gamma2, float* dgamma2, float* dbeta2, bf16_t* dy2,
+                        hipStream_t s) {
+  check_channels(C, P);
+  if (ws == ws2) throw std::invalid_argument("bn_bwd_dual: the two layers need separate workspaces");
+  const int G = reduce_grid(P, C);
+  BnBwdArgs a{dz, y1, nullptr, mask, mean1, invstd1, gamma1, dgamma1, dbeta1, dy1, nullptr, ws, G,
+              P, C, 0, y2, mean2, invstd2, gamma2, dgamma2, dbeta2, dy2, ws2};
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, dim3(G), dim3(TPB), 0, s, a);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, a);
+  BnBwdArgs b = a;                   // the finalize kernel reads the first layer's fields
+  b.ws = ws2; b.dgamma = dgamma2; b.dbeta = dbeta2; b.mean = mean2; b.invstd = invstd2;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, b);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<false, 2>), dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
 }

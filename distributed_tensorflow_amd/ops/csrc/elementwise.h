@@ -25,6 +25,12 @@ void launch_bn_pool_bwd(const bf16_t* dzp, const uint8_t* idx, const bf16_t* y, 
                         const float* invstd, const float* gamma, float* dgamma, float* dbeta,
                         bf16_t* dy, float* ws, int N, int H, int W, int C, int OH, int OW, int k,
                         int stride, int pt, int pl, hipStream_t s);
+void launch_bn_bwd_dual(const bf16_t* dz, const uint8_t* mask, int P, int C, float* ws, float* ws2,
+                        const bf16_t* y1, const float* mean1, const float* invstd1,
+                        const float* gamma1, float* dgamma1, float* dbeta1, bf16_t* dy1,
+                        const bf16_t* y2, const float* mean2, const float* invstd2,
+                        const float* gamma2, float* dgamma2, float* dbeta2, bf16_t* dy2,
+                        hipStream_t s);
 void launch_bn_infer(const bf16_t* y, const bf16_t* res, bf16_t* z, const float* gamma,
                      const float* beta, const float* mm, const float* mv, int P, int C, float eps,
                      int relu, hipStream_t s);

@@ -180,6 +180,34 @@ def test_deferred_projection_data_gradient_matches_plain_order(monkeypatch):
     assert a.norm().item() == pytest.approx(b.norm().item(), rel=3e-2), name
 
 
+def test_dual_batchnorm_backward_matches_separate_launches(monkeypatch):
+  """ResNet-50's projection blocks run the backward of the block's last BatchNorm and of the
+  shortcut's BatchNorm as one pair of sweeps; gradients must match the separate launches."""
+  from distributed_tensorflow_amd.engine.hip_executor import HipExecutor
+  dev = torch.device("cuda")
+  spec = models.resnet50()
+  g = torch.Generator().manual_seed(6)
+  x = (torch.randn(8, 224, 224, 3, generator=g) * 60 + 120).to(dev)
+  y = torch.randint(0, 1001, (8,), generator=g).to(dev)
+  monkeypatch.setenv("DTF_BN_FUSED_STATS", "0")            # deterministic forward
+  res = []
+  for dual in ("1", "0"):
+    monkeypatch.setenv("DTF_BN_DUAL_BWD", dual)
+    st = ParamStore(spec, dev, 0)
+    ex = HipExecutor(spec, st, 8, "bf16", st.make_buckets(1), use_graph=False)
+    loss, _ = ex.train_step(x, y)
+    torch.cuda.synchronize()
+    res.append((loss.item(), st.grads.clone(), ex.bwd_plan.size()))
+  assert res[0][2] == res[1][2] - 4                 # four projection blocks
+  for name in ("conv1/kernel", "res2a_branch1/kernel", "bn2a_branch1/gamma", "bn2a_branch2c/beta",
+               "res5a_branch1/kernel", "bn5a_branch1/gamma", "res4a_branch2c/kernel"):
+    e = st.entries[name]
+    a = res[0][1][e.offset:e.offset + e.size]
+    b = res[1][1][e.offset:e.offset + e.size]
+    assert _cos(a, b) > 0.995, name
+    assert a.norm().item() == pytest.approx(b.norm().item(), rel=3e-2), name
+
+
 def test_training_reduces_loss_and_graph_replay_matches_eager():
   from distributed_tensorflow_amd.engine.hip_executor import HipExecutor
   dev = torch.device("cuda")

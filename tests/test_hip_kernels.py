@@ -514,6 +514,56 @@ def test_batchnorm_relu_maxpool_fused(N, H, W, C):
   assert bad.float().mean().item() < 1e-3            # a near-tie may pick another tap
 
 
+@pytest.mark.parametrize("C,P", [(64, 3001), (512, 777), (2048, 130)])
+def test_batchnorm_backward_dual_matches_two_single_launches(C, P):
+  """Two BatchNorm layers fed by the same masked gradient (a block's last layer and its
+  projection shortcut's, reference `resnet_model.py:204-219`): the dual sweeps must give what
+  two separate backward launches give."""
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator().manual_seed(C + P)
+  dz = _bf(torch.randn(P, C, generator=gen)).to(dev)
+  bits = torch.rand(P, C, generator=gen) > 0.45
+  mask = (bits.view(P, C // 8, 8).to(torch.int32) << torch.arange(8)).sum(-1).to(torch.uint8)
+  mask = torch.cat([mask.flatten(), torch.zeros(4, dtype=torch.uint8)]).to(dev)
+  ws = torch.zeros(native.ext().bn_workspace_floats(), device=dev)
+  ws2 = torch.zeros_like(ws)
+  layers = []
+  for i in range(2):
+    y = _bf(torch.randn(P, C, generator=gen) * (1.5 + i) + 0.4 * i).to(dev)
+    mean = y.float().mean(0)
+    invstd = torch.rsqrt(y.float().var(0, unbiased=False) + 1e-5)
+    gamma = (torch.rand(C, generator=gen) + 0.5).to(dev)
+    layers.append(dict(y=y, mean=mean.contiguous(), invstd=invstd.contiguous(), gamma=gamma))
+  single = []
+  for L in layers:
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dy = torch.empty(P, C, dtype=torch.bfloat16, device=dev)
+    native.run_op("bn_bwd", dict(dz=dz.data_ptr(), y=L["y"].data_ptr(), z=None, mask=mask.data_ptr(),
+                                 mean=L["mean"].data_ptr(), invstd=L["invstd"].data_ptr(),
+                                 gamma=L["gamma"].data_ptr(), dgamma=dg.data_ptr(),
+                                 dbeta=db.data_ptr(), dy=dy.data_ptr(), dres=None,
+                                 ws=ws.data_ptr(), P=P, C=C))
+    torch.cuda.synchronize()
+    single.append((dg, db, dy))
+  out = [(torch.zeros(C, device=dev), torch.zeros(C, device=dev),
+          torch.full((P, C), float("nan"), dtype=torch.bfloat16, device=dev)) for _ in range(2)]
+  A, B = layers
+  native.run_op("bn_bwd_dual", dict(
+      dz=dz.data_ptr(), mask=mask.data_ptr(), P=P, C=C, ws=ws.data_ptr(), ws2=ws2.data_ptr(),
+      y=A["y"].data_ptr(), mean=A["mean"].data_ptr(), invstd=A["invstd"].data_ptr(),
+      gamma=A["gamma"].data_ptr(), dgamma=out[0][0].data_ptr(), dbeta=out[0][1].data_ptr(),
+      dy=out[0][2].data_ptr(),
+      y2=B["y"].data_ptr(), mean2=B["mean"].data_ptr(), invstd2=B["invstd"].data_ptr(),
+      gamma2=B["gamma"].data_ptr(), dgamma2=out[1][0].data_ptr(), dbeta2=out[1][1].data_ptr(),
+      dy2=out[1][2].data_ptr()))
+  torch.cuda.synchronize()
+  for (dg, db, dy), (dg2, db2, dy2) in zip(single, out):
+    assert torch.allclose(dg, dg2, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(db, db2, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(dy.float(), dy2.float(), rtol=1e-2, atol=1e-2)
+
+
 def test_pooling():
   native = _native()
   dev = torch.device("cuda")
