@@ -199,6 +199,28 @@ class HipExecutor:
           self._bn_pool[b.name] = users[0]
           self._pool_bn[users[0].name] = b
 
+    # ---- BatchNorm of a projection shortcut (no ReLU, no residual) whose only consumer is
+    # another BatchNorm that takes it as its residual: its normalised output is never
+    # materialised in training, the consumer applies scale / shift to the shortcut
+    # convolution's output while adding it
+    self._bn_lazy: Dict[str, Op] = {}        # BatchNorm name -> consumer
+    self._bn_lazy_out: Dict[str, Op] = {}    # its output tensor -> the BatchNorm
+    if os.environ.get("DTF_BN_LAZY_SHORTCUT", "1") != "0":
+      users: Dict[str, List[Op]] = {}
+      for op in spec.ops:
+        for t in op.inputs:
+          users.setdefault(t, []).append(op)
+      for b in spec.ops:
+        u = users.get(b.output, [])
+        if (b.kind == "bn" and not b.attrs["relu"] and len(b.inputs) == 1 and len(u) == 1
+            and u[0].kind == "bn" and len(u[0].inputs) > 1 and u[0].inputs[1] == b.output
+            and u[0].inputs[0] != b.output and u[0].name not in self._bn_pool
+            and b.output != spec.logits_name
+            and tuple(acts[b.inputs[0]].shape) == tuple(acts[u[0].inputs[0]].shape)
+            and b.attrs["channels"] == u[0].attrs["channels"]):
+          self._bn_lazy[b.name] = u[0]
+          self._bn_lazy_out[b.output] = b
+
     # ---- BatchNorm side buffers -------------------------------------------------------------
     bn_ops = [o for o in spec.ops if o.kind == "bn"]
     tot = sum(o.attrs["channels"] for o in bn_ops)
@@ -397,10 +419,21 @@ class HipExecutor:
           ws = (self.bn_stats.data_ptr() + 4 * self._bn_stats_off[op.name]) if fused \
               else self.bn_ws.data_ptr()
           mask = self._bn_mask[op.name].data_ptr() if op.name in self._bn_mask else None
+          extra = {}
+          if op.name in self._bn_lazy:
+            # projection shortcut: statistics only; the block's last BatchNorm normalises this
+            # layer's input on the fly when it adds the residual
+            extra["apply"] = 0
+          elif len(op.inputs) > 1 and op.inputs[1] in self._bn_lazy_out:
+            src = self._bn_lazy_out[op.inputs[1]]
+            sp = self.bn_saved.data_ptr() + 4 * self._bn_off[src.name]
+            cs = src.attrs["channels"]
+            common["res"] = acts[src.inputs[0]].data_ptr()
+            extra.update(rscale=sp + 8 * cs, rshift=sp + 12 * cs)
           plan.add("bn_fwd_train", dict(
               save_mean=mean_p, save_invstd=mean_p + 4 * C, scale=mean_p + 8 * C,
               shift=mean_p + 12 * C, ws=ws, fused_replicas=self.STATS_REPLICAS if fused else 0,
-              mask=mask, momentum=float(at["momentum"]), **common), op.name)
+              mask=mask, momentum=float(at["momentum"]), **common, **extra), op.name)
         else:
           plan.add("bn_infer", common, op.name)
       elif op.kind == "maxpool":

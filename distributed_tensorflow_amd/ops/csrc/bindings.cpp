@@ -143,9 +143,12 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     const int P = get<int>(d, "P"), C = get<int>(d, "C");
     const float eps = get<float>(d, "eps"), mom = get<float>(d, "momentum");
     const int relu = get<int>(d, "relu");
+    // residual = input of another BatchNorm, normalised on the fly with that layer's constants
+    auto rscale = ptr<const float>(d, "rscale", false); auto rshift = ptr<const float>(d, "rshift", false);
+    const int apply = get_or<int>(d, "apply", 1);      // 0: statistics + finalize only
     return [=](hipStream_t s) {
       launch_bn_fwd_train(y, res, z, mask, gamma, beta, mm, mv, smean, sinv, scale, shift, ws,
-                          fused, P, C, eps, mom, relu, s);
+                          fused, P, C, eps, mom, relu, rscale, rshift, apply, s);
     };
   }
   if (kind == "bn_pool_fwd_train" || kind == "bn_pool_bwd") {

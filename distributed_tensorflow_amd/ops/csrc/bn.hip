@@ -205,6 +205,10 @@ struct BnApplyArgs {
   // FOLD: the finalize step runs in the prologue of every block (see fold_columns)
   const float* fws; int fG; float momentum;
   float* umm; float* umv; float* save_mean; float* save_invstd; float* oscale; float* oshift;
+  // Residual given as the *input* of another BatchNorm (the projection shortcut's, which has
+  // no ReLU) plus that layer's scale / shift: res := res * rscale + rshift on the fly, so the
+  // shortcut's normalised tensor is never written or read back.
+  const float* rscale; const float* rshift;
 };
 
 // Column sums of G rows of `cols` floats (cols = 2 * C <= 512, a power of two >= 16) by one
@@ -284,6 +288,12 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
   // t in a pass sits at  row0 * tpr + t,  and row0 * tpr is a multiple of 256.  Four passes
   // are loaded before any is used: with one 16-byte load per thread in flight the sweep is
   // latency bound at about half of what the memory system delivers.
+  float rsc[8], rsh[8];
+  const bool raff = a.rscale != nullptr;
+  if (raff) {
+    load8(a.rscale + chunk * 8, rsc);
+    load8(a.rshift + chunk * 8, rsh);
+  }
   constexpr int U = 4;
   const int stride = gridDim.x * rpb;
   for (int row0 = blockIdx.x * rpb; row0 < a.P; row0 += U * stride) {
@@ -310,6 +320,10 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
         if (a.res) {
           float r[8];
           unpack8(rq[u], r);
+          if (raff) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) r[c] = r[c] * rsc[c] + rsh[c];
+          }
 #pragma unroll
           for (int c = 0; c < 8; ++c) f[c] += r[c];
         }
@@ -799,8 +813,11 @@ void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, uint8_t*
                          const float* gamma, const float* beta, float* mm, float* mv,
                          float* save_mean, float* save_invstd, float* scale, float* shift,
                          float* ws, int fused_replicas, int P, int C, float eps, float momentum,
-                         int relu, hipStream_t s) {
+                         int relu, const float* rscale, const float* rshift, int apply,
+                         hipStream_t s) {
   check_channels(C, P);
+  if ((rscale == nullptr) != (rshift == nullptr) || (rscale && !res))
+    throw std::invalid_argument("bn_fwd_train: rscale / rshift come together, with res");
   int G = fused_replicas;             // > 0: `ws` already holds that many rows of [2][C] sums
   if (G <= 0) {
     G = reduce_grid(P, C);
@@ -811,15 +828,17 @@ void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, uint8_t*
     return !(e && e[0] == '0');
   }();
   BnApplyArgs a{y, res, z, mask, scale, shift, gamma, beta, mm, mv, P, C, eps, relu,
-                ws, G, momentum, mm, mv, save_mean, save_invstd, scale, shift};
-  if (fold_ok && fused_replicas > 0 && fused_replicas * 2 * C <= 16384 && C <= FOLD_MAX_C) {
+                ws, G, momentum, mm, mv, save_mean, save_invstd, scale, shift, rscale, rshift};
+  if (apply && fold_ok && fused_replicas > 0 && fused_replicas * 2 * C <= 16384 &&
+      C <= FOLD_MAX_C) {
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
     return;
   }
   BnFinalizeArgs f{ws, G, gamma, beta, mm, mv, save_mean, save_invstd, scale, shift,
                    P, C, eps, momentum};
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, f);
-  hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
+  if (apply)      // apply == 0: statistics only, a later layer normalises this tensor on the fly
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
 }
 
 namespace {
@@ -900,7 +919,8 @@ void launch_bn_infer(const bf16_t* y, const bf16_t* res, bf16_t* z, const float*
                      int relu, hipStream_t s) {
   check_channels(C, P);
   BnApplyArgs a{y, res, z, nullptr, nullptr, nullptr, gamma, beta, mm, mv, P, C, eps, relu,
-                nullptr, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                nullptr, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                nullptr, nullptr};
   hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
 }
 

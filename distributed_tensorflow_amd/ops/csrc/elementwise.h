@@ -10,7 +10,8 @@ void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, uint8_t*
                          const float* gamma, const float* beta, float* mm, float* mv,
                          float* save_mean, float* save_invstd, float* scale, float* shift,
                          float* ws, int fused_replicas, int P, int C, float eps, float momentum,
-                         int relu, hipStream_t s);
+                         int relu, const float* rscale, const float* rshift, int apply,
+                         hipStream_t s);
 // Folded inference constants of every BatchNorm layer (descriptor layout: see bn.hip).
 int bn_fold_desc_size();
 void launch_bn_fold(const float* params, const float* state, float* out, const void* descs,

@@ -564,6 +564,45 @@ def test_batchnorm_backward_dual_matches_two_single_launches(C, P):
     assert torch.allclose(dy.float(), dy2.float(), rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("C", [64, 1024])
+def test_batchnorm_forward_with_lazily_normalised_residual(C):
+  """`apply=0` leaves only the statistics / constants of a layer; a second layer then adds
+  that layer's *input* as residual, normalising it on the fly (rscale / rshift)."""
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator().manual_seed(C)
+  P = 1500
+  y1 = _bf(torch.randn(P, C, generator=gen) * 3 + 1).to(dev)
+  y2 = _bf(torch.randn(P, C, generator=gen) * 2 - 0.5).to(dev)
+  ws = torch.zeros(native.ext().bn_workspace_floats(), device=dev)
+  pars = []
+  for _ in range(2):
+    pars.append(dict(gamma=(torch.rand(C, generator=gen) + 0.5).to(dev),
+                     beta=(torch.randn(C, generator=gen) * 0.2).to(dev),
+                     mm=torch.zeros(C, device=dev), mv=torch.ones(C, device=dev),
+                     saved=torch.zeros(4 * C, device=dev)))
+  def args(p, y, **kw):
+    sv = p["saved"].data_ptr()
+    return dict(y=y.data_ptr(), gamma=p["gamma"].data_ptr(), beta=p["beta"].data_ptr(),
+                mm=p["mm"].data_ptr(), mv=p["mv"].data_ptr(), save_mean=sv, save_invstd=sv + 4 * C,
+                scale=sv + 8 * C, shift=sv + 12 * C, ws=ws.data_ptr(), P=P, C=C, eps=1e-5,
+                momentum=0.9, **kw)
+  untouched = torch.full((P, C), 7.0, dtype=torch.bfloat16, device=dev)
+  native.run_op("bn_fwd_train", args(pars[0], y1, res=None, z=untouched.data_ptr(), relu=0, apply=0))
+  z = torch.empty(P, C, dtype=torch.bfloat16, device=dev)
+  sv = pars[0]["saved"].data_ptr()
+  native.run_op("bn_fwd_train", args(pars[1], y2, res=y1.data_ptr(), z=z.data_ptr(), relu=1,
+                                     rscale=sv + 8 * C, rshift=sv + 12 * C))
+  torch.cuda.synchronize()
+  assert (untouched.float() == 7.0).all()                   # apply=0 wrote no activation
+  def bn(y, p):
+    y = y.float()
+    return (y - y.mean(0)) * torch.rsqrt(y.var(0, unbiased=False) + 1e-5) * p["gamma"] + p["beta"]
+  ref = torch.relu(bn(y2, pars[1]) + bn(y1, pars[0]))
+  assert torch.allclose(z.float(), ref, rtol=2e-2, atol=2e-2)
+  assert torch.allclose(pars[0]["mm"], 0.1 * y1.float().mean(0), rtol=1e-3, atol=1e-4)
+
+
 def test_pooling():
   native = _native()
   dev = torch.device("cuda")
