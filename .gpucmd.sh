@@ -1,6 +1,6 @@
 cd /root/repo
-timeout -k 10 600 python -u -m pytest tests/test_hip_kernels.py tests/test_hip_executor.py -x -q --timeout 180 --timeout-method thread > gpurun_out/t_lazy.log 2>&1 || { tail -n 40 gpurun_out/t_lazy.log; exit 1; }
-tail -n 2 gpurun_out/t_lazy.log
-for f in 1 0 1 0; do
-DTF_BN_LAZY_SHORTCUT=$f timeout -k 10 200 python bench.py --steps 60 --warmup 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('r50 lazy=$f', d['ms_per_step'], d['value'])"
-done
+export TMPDIR=/tmp
+timeout -k 10 400 python scripts/debug/check_resnet50_bs256.py > gpurun_out/numerics_now.txt 2>&1 || { tail -n 30 gpurun_out/numerics_now.txt; exit 1; }
+tail -n 16 gpurun_out/numerics_now.txt
+OUT=gpurun_out/profile_step2 timeout -k 10 500 sh scripts/profile_step.sh > gpurun_out/profile_step2.txt 2>&1 || { tail -n 30 gpurun_out/profile_step2.txt; exit 1; }
+timeout -k 10 200 python bench.py --steps 300 --warmup 10 2>/dev/null
