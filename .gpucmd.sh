@@ -1,6 +1,4 @@
 cd /root/repo
-timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread > gpurun_out/gpu_tests2.log 2>&1 || { tail -n 40 gpurun_out/gpu_tests2.log; exit 1; }
-tail -n 2 gpurun_out/gpu_tests2.log
-timeout -k 10 200 python bench.py --steps 100 --warmup 10 --rehearse_collectives 2>/dev/null
-timeout -k 10 200 python bench.py --steps 100 --warmup 10 --rehearse_collectives --num_packs 8 2>/dev/null | cut -c1-200
-timeout -k 10 200 python bench.py --steps 100 --warmup 10 --rehearse_collectives --num_packs 2 2>/dev/null | cut -c1-200
+for f in 384 512 768 1024 1536; do
+DTF_WGRAD_TARGET_BLOCKS=$f DTF_AUTOTUNE_IGNORE_CACHE=0 timeout -k 10 200 python bench.py --steps 60 --warmup 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('r50 target=$f', d['ms_per_step'], d['value'])"
+done

@@ -1,4 +1,4 @@
-"""Multi-process tests of the distribution strategies on CPU (`gloo`, world size 2-3).
+"""Multi-process tests of the distribution strategies on CPU (`gloo`, world size 2-8).
 
 They use the framework's own launcher to start one process per rank on localhost - the
 same trick the reference uses for manual testing (two terminals with `localhost:8080/8081`,
@@ -118,6 +118,37 @@ strat.barrier()
   assert torch.allclose(got, ref, rtol=1e-4, atol=1e-6)
   ref_c = shards[0].view("conv1/kernel").flatten()[:16]
   assert torch.allclose(torch.tensor(res[0]["conv1"]), ref_c, rtol=1e-3, atol=1e-6)
+
+
+def test_mirrored_eight_ranks_stay_in_sync(tmp_path):
+  """The 8-replica job of the scaling benchmark, rehearsed on CPU: eight ranks, four fusion
+  buckets, different initial seeds and different data per rank; after the broadcast and two
+  steps every replica holds the same variables and the same reduced gradients."""
+  body = COMMON + """
+torch.set_num_threads(1)
+strat = S.get_distribution_strategy("mirrored", num_gpus=0, all_reduce_alg=None, num_packs=4)
+assert strat.num_replicas_in_sync == world == 8
+m = Model(models.resnet20(), strategy=strat, dtype="fp32", seed=rank)
+m.compile(SGD(0.05, momentum=0.9), "sparse_categorical_crossentropy", ["sparse_categorical_accuracy"])
+g2 = torch.Generator().manual_seed(1000 + rank)
+xs = torch.randn(2, 32, 32, 3, generator=g2) * 50 + 100
+ys = torch.randint(0, 10, (2, 1), generator=g2).float()
+for _ in range(2):
+  l, c = m.train_on_batch(xs, ys)
+red = m._grad_reducer()
+save({"params": m.store.params.double().sum().item(), "state": m.store.state.double().sum().item(),
+      "grads": m.store.grads.double().sum().item(), "head": m.store.params[:8].tolist(),
+      "buckets": len(red.buckets), "collectives": red.collectives_launched, "loss": l.item()})
+strat.barrier()
+"""
+  res = _run_ranks(tmp_path, body, 8, timeout=600)
+  assert len(res) == 8
+  for r in res[1:]:
+    assert r["params"] == res[0]["params"] and r["head"] == res[0]["head"]
+    assert r["grads"] == res[0]["grads"]
+  assert res[0]["buckets"] >= 4 and res[0]["collectives"] == 2 * res[0]["buckets"]
+  # moving statistics are per replica (no SyncBN in the reference): they differ with the data
+  assert len({r["state"] for r in res}) > 1
 
 
 def test_deterministic_replica_gradient_check(tmp_path):
