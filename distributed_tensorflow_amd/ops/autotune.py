@@ -9,7 +9,9 @@ this file - the file in the tree holds the shapes of the bundled models measured
 so a normal run only does dictionary look-ups; shapes that are not in the cache fall back to the
 heuristics of `conv_plan.pick_fwd_cfg` / `pick_wgrad_cfg` unless tuning is switched on with
 `DTF_AUTOTUNE=1` (new entries are then written to `DTF_AUTOTUNE_OUT` or the cache file;
-`DTF_AUTOTUNE_CACHE` reads another cache file, `DTF_AUTOTUNE_IGNORE_CACHE=1` starts empty).
+`DTF_AUTOTUNE_CACHE` reads another cache file, `DTF_AUTOTUNE_IGNORE_CACHE=1` starts empty,
+`DTF_AUTOTUNE_RETUNE=conv` / `wgrad` / `conv,wgrad` measures the entries of that kind again and
+keeps the rest - the thing to do after changing one of the two kernels).
 """
 from __future__ import annotations
 
@@ -59,8 +61,15 @@ def signature(kind: str, desc: Dict) -> str:
   return "|".join(parts)
 
 
+_retuned = set()
+
+
 def lookup(kind: str, desc: Dict) -> Optional[Dict[str, int]]:
-  return _load().get(signature(kind, desc))
+  sig = signature(kind, desc)
+  if enabled() and kind in os.environ.get("DTF_AUTOTUNE_RETUNE", "").split(",") \
+      and sig not in _retuned:
+    return None
+  return _load().get(sig)
 
 
 def _fwd_candidates(desc: Dict) -> List[int]:
@@ -69,9 +78,11 @@ def _fwd_candidates(desc: Dict) -> List[int]:
     return [3, 2]
   if cout <= 32:
     return [2, 1]
+  # 16..: the multi-stage pipeline of conv_pipe.hip (descriptors it cannot serve fall back to
+  # the two-stage tile of the same footprint, so listing them is always safe)
   if cout <= 64:
-    return [1, 5, 0]
-  return [0, 6, 4, 5, 1]
+    return [1, 5, 0, 21, 22, 23, 20]
+  return [0, 6, 4, 5, 1, 16, 17, 18, 19, 20, 21, 24, 25, 26, 27]
 
 
 def _wgrad_candidates(desc: Dict) -> List[Tuple[int, int]]:
@@ -90,6 +101,19 @@ def _wgrad_candidates(desc: Dict) -> List[Tuple[int, int]]:
     cfgs = [c for c in cfgs if conv_plan.WGRAD_CFGS[c][0] <= 64] or cfgs
   out = []
   max_splits = max(P // 256, 1)
+
+  def with_depths(c, s):
+    """(c, s) plus its deep-pipeline variants (cfg + 64 * (stages - 2)): tiles whose waves all
+    issue the same loads per step (both sides at least 64 wide), while the ring fits the LDS."""
+    res = [(c, s)]
+    bkk, bco = conv_plan.WGRAD_CFGS[c % 16]
+    g = 1 << (c // 16)
+    if bkk >= 64 and bco >= 64:
+      for stages in (3, 4):
+        if g * stages * 32 * (bkk + bco) * 2 <= 160 * 1024:
+          res.append((c + 64 * (stages - 2), s))
+    return res
+
   for c in cfgs:
     bkk, bco = conv_plan.WGRAD_CFGS[c]
     tiles = -(-ktotal // bkk) * -(-cout // bco)
@@ -99,12 +123,12 @@ def _wgrad_candidates(desc: Dict) -> List[Tuple[int, int]]:
       if s in seen:
         continue
       seen.add(s)
-      out.append((c, s))
+      out.extend(with_depths(c, s))
       # 2 / 4 wave groups per block share one atomic epilogue: same resident waves with
       # half / a quarter of the blocks (cfg + 16 * log2(groups)); the 8-wave tile allows 2
       for lg, g in ((1, 2), (2, 4)):
         if s >= g and not (c == 8 and g == 4) and (c + 16 * lg, -(-s // g)) not in out:
-          out.append((c + 16 * lg, -(-s // g)))
+          out.extend(with_depths(c + 16 * lg, -(-s // g)))
   return out
 
 
@@ -143,6 +167,7 @@ def tune(kind: str, desc: Dict) -> Dict[str, int]:
   else:
     raise ValueError("nothing to tune for op kind %r" % kind)
   best["us"] = round(best_t * 1000.0, 1)
+  _retuned.add(signature(kind, desc))
   _load()[signature(kind, desc)] = best
   _dirty = True
   return best

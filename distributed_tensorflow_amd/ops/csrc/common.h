@@ -59,6 +59,14 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Direct-to-LDS loads (global_load_lds) are ordered for a following ds_read only by the issuing
+// wave's own vector-memory wait followed by a barrier; the compiler's wait insertion does not
+// reliably track them (it has been seen to omit the wait across a loop back edge), so every
+// kernel that reads a DMA-filled tile states the wait itself before the barrier.
+__device__ __forceinline__ void dma_wait_all() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // Unsigned division by a run-time constant with a precomputed multiplier
 // (q = (n * mul) >> 32 >> shift); exact for n < 2^31. Built on the host by make_fastdiv().
 struct FastDiv {

@@ -1,0 +1,247 @@
+// Epilogue of the implicit-GEMM convolution kernels (shared by conv_igemm.hip and conv_pipe.hip).
+//
+// A lane of a wave that owns a WM x WN sub-tile holds, for each of its MR pixels (MFMA column
+// fr = lane & 15 of pixel block mr), CPL = 4*NR consecutive output channels starting at
+// co0 = n0 + wn*WN + (lane >> 4)*CPL: accumulator acc[nr][mr][e] is channel co0 + 4*nr + e.
+// The epilogue adds bias / addend (optionally gated by a 1-bit mask), applies the folded
+// BatchNorm of the inference flavour, stores 16 bytes per lane and accumulates the fused
+// BatchNorm statistics (forward: sum, sum of squares; backward: sum g, sum g*y).
+#pragma once
+#include "common.h"
+#include "conv_params.h"
+
+namespace conv_epi {
+
+constexpr int EPI_PLAIN = 0, EPI_BSTATS = 1, EPI_INFER = 2;
+
+// Sum over the 16 lanes that share lane/16 (the 16 pixels of an MFMA column block), leaving
+// the totals scattered over those lanes: a halving butterfly - at step T a lane keeps one
+// half of its values and hands the other half to lane ^ (1 << T) - so NV values cost NV - 1
+// shuffles in total instead of 4 * NV.  Afterwards v[0 .. (NV >> steps) - 1] of a lane hold the
+// totals of the original indices  base + j,  base = sum_T bit_T(lane) * (NV >> (T + 1)).
+template <int NV, int N, int T>
+__device__ __forceinline__ void butterfly16(float (&v)[NV], int fr) {
+  if constexpr (T < 4) {
+    if constexpr (N > 1) {
+      constexpr int H = N / 2;
+      const bool up = (fr >> T) & 1;
+#pragma unroll
+      for (int i = 0; i < H; ++i) {
+        const float send = up ? v[i] : v[i + H];
+        const float keep = up ? v[i + H] : v[i];
+        v[i] = keep + __shfl_xor(send, 1 << T);
+      }
+      butterfly16<NV, H, T + 1>(v, fr);
+    } else {
+      v[0] += __shfl_xor(v[0], 1 << T);
+      butterfly16<NV, 1, T + 1>(v, fr);
+    }
+  }
+}
+
+
+// m_base: first pixel row of this wave's sub-tile (m0 + wm*WM); co0: see above; mt: M-tile
+// index of the block (selects the statistics replica).
+template <int MR, int NR, bool POINTWISE, int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[NR][MR],
+                                              const int m_base, const int co0, const int mt,
+                                              const int lane) {
+  constexpr bool BSTATS = EPI == EPI_BSTATS;
+  const int fr = lane & 15;
+  // ---- epilogue: lane holds 4*NR consecutive channels of pixel (mr, fr) ---------------------
+  constexpr int CPL = 4 * NR;                      // channels per lane
+  float bias[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c)
+    bias[c] = (p.bias != nullptr && co0 + c < p.Cout) ? p.bias[co0 + c] : 0.f;
+  if constexpr (EPI == EPI_INFER) {
+    // tile nr of a lane holds channels co0 + 4*nr .. co0 + 4*nr + 3
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+      float sc[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        sc[e] = (co0 + nr * 4 + e < p.Cout) ? p.scale[co0 + nr * 4 + e] : 0.f;
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[nr][mr][e] *= sc[e];
+    }
+  }
+  const bool do_relu = EPI == EPI_INFER && p.relu != 0;
+  const bool vec_ok = (p.ldc % 8 == 0);
+  // fused batch-norm statistics: [0, CPL) sums, [CPL, 2*CPL) sums of squares of this lane's
+  // channels over its MR pixels (the host guarantees the vector store path in that case)
+  float st[2 * CPL];
+#pragma unroll
+  for (int c = 0; c < 2 * CPL; ++c) st[c] = 0.f;
+#pragma unroll
+  for (int mr = 0; mr < MR; ++mr) {
+    const int m = m_base + mr * 16 + fr;
+    if (m >= p.M) continue;
+    size_t opix;                                   // linear pixel index in the output tensor
+    if (POINTWISE) {
+      opix = (size_t)m;
+    } else {
+      const uint32_t t = fd_div((uint32_t)m, p.divOW);
+      const int ow = m - (int)t * p.OW;
+      const uint32_t n = fd_div(t, p.divOH);
+      const int oh = (int)t - (int)n * p.OH;
+      opix = (size_t)((int)n * p.OHfull + oh * p.OSH + p.OOH) * p.OWfull + (ow * p.OSW + p.OOW);
+    }
+    const size_t obase = opix * p.ldc;
+    bf16_t* optr = p.out + obase + co0;
+    const bf16_t* aptr = p.addend ? p.addend + obase + co0 : nullptr;
+    const uint8_t* mptr = p.addend_mask ? p.addend_mask + opix * (p.ldc >> 3) + (co0 >> 3) : nullptr;
+    if constexpr (CPL >= 8) {
+#pragma unroll
+      for (int h = 0; h < CPL / 8; ++h) {
+        // channels h*8 .. h*8+7 of this lane = MFMA tiles nr = 2h, 2h+1
+        float v0 = acc[2 * h][mr][0] + bias[h * 8 + 0], v1 = acc[2 * h][mr][1] + bias[h * 8 + 1];
+        float v2 = acc[2 * h][mr][2] + bias[h * 8 + 2], v3 = acc[2 * h][mr][3] + bias[h * 8 + 3];
+        float v4 = acc[2 * h + 1][mr][0] + bias[h * 8 + 4], v5 = acc[2 * h + 1][mr][1] + bias[h * 8 + 5];
+        float v6 = acc[2 * h + 1][mr][2] + bias[h * 8 + 6], v7 = acc[2 * h + 1][mr][3] + bias[h * 8 + 7];
+        if (vec_ok && co0 + h * 8 + 8 <= p.Cout) {
+          if (aptr) {
+            u32x4 a = *reinterpret_cast<const u32x4*>(aptr + h * 8);
+            if (mptr) {                            // keep only the elements whose mask bit is set
+              const uint32_t b = mptr[h];
+              a.x &= ((b & 1u) ? 0xffffu : 0u) | ((b & 2u) ? 0xffff0000u : 0u);
+              a.y &= ((b & 4u) ? 0xffffu : 0u) | ((b & 8u) ? 0xffff0000u : 0u);
+              a.z &= ((b & 16u) ? 0xffffu : 0u) | ((b & 32u) ? 0xffff0000u : 0u);
+              a.w &= ((b & 64u) ? 0xffffu : 0u) | ((b & 128u) ? 0xffff0000u : 0u);
+            }
+            v0 += __uint_as_float(a.x << 16); v1 += __uint_as_float(a.x & 0xffff0000u);
+            v2 += __uint_as_float(a.y << 16); v3 += __uint_as_float(a.y & 0xffff0000u);
+            v4 += __uint_as_float(a.z << 16); v5 += __uint_as_float(a.z & 0xffff0000u);
+            v6 += __uint_as_float(a.w << 16); v7 += __uint_as_float(a.w & 0xffff0000u);
+          }
+          if (do_relu) {
+            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+            v4 = fmaxf(v4, 0.f); v5 = fmaxf(v5, 0.f); v6 = fmaxf(v6, 0.f); v7 = fmaxf(v7, 0.f);
+          }
+          u32x4 o;
+          o.x = pack2bf(v0, v1); o.y = pack2bf(v2, v3); o.z = pack2bf(v4, v5); o.w = pack2bf(v6, v7);
+          *reinterpret_cast<u32x4*>(optr + h * 8) = o;
+          if (EPI != EPI_INFER && p.stats) {
+            const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+            if constexpr (BSTATS) {                  // sum g, sum g * y  (g = masked output)
+              const u32x4 yq = *reinterpret_cast<const u32x4*>(p.stats_y + obase + co0 + h * 8);
+              const uint32_t yw[4] = {yq.x, yq.y, yq.z, yq.w};
+              const uint32_t sb = p.stats_mask
+                  ? p.stats_mask[opix * (p.ldc >> 3) + (co0 >> 3) + h] : 0xffu;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float lo = (sb >> (2 * j)) & 1u ? __uint_as_float(w[j] << 16) : 0.f;
+                const float hi = (sb >> (2 * j + 1)) & 1u ? __uint_as_float(w[j] & 0xffff0000u) : 0.f;
+                st[h * 8 + 2 * j] += lo;
+                st[h * 8 + 2 * j + 1] += hi;
+                st[CPL + h * 8 + 2 * j] += lo * __uint_as_float(yw[j] << 16);
+                st[CPL + h * 8 + 2 * j + 1] += hi * __uint_as_float(yw[j] & 0xffff0000u);
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+                st[h * 8 + 2 * j] += lo;
+                st[h * 8 + 2 * j + 1] += hi;
+                st[CPL + h * 8 + 2 * j] += lo * lo;
+                st[CPL + h * 8 + 2 * j + 1] += hi * hi;
+              }
+            }
+          }
+        } else {
+          const float vv[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            if (co0 + h * 8 + c < p.Cout) {
+              float x = vv[c];
+              if (aptr) x += bf2f(aptr[h * 8 + c]);
+              optr[h * 8 + c] = f2bf(do_relu ? fmaxf(x, 0.f) : x);
+            }
+          }
+        }
+      }
+    } else {
+      // CPL == 4: one 8-byte store
+      float v0 = acc[0][mr][0] + bias[0], v1 = acc[0][mr][1] + bias[1];
+      float v2 = acc[0][mr][2] + bias[2], v3 = acc[0][mr][3] + bias[3];
+      if (p.ldc % 4 == 0 && co0 + 4 <= p.Cout) {
+        if (aptr) {
+          u32x2 a = *reinterpret_cast<const u32x2*>(aptr);
+          if (mptr) {                              // this lane's 4 channels: one nibble of the byte
+            const uint32_t b = (uint32_t)mptr[0] >> (co0 & 4);
+            a.x &= ((b & 1u) ? 0xffffu : 0u) | ((b & 2u) ? 0xffff0000u : 0u);
+            a.y &= ((b & 4u) ? 0xffffu : 0u) | ((b & 8u) ? 0xffff0000u : 0u);
+          }
+          v0 += __uint_as_float(a.x << 16); v1 += __uint_as_float(a.x & 0xffff0000u);
+          v2 += __uint_as_float(a.y << 16); v3 += __uint_as_float(a.y & 0xffff0000u);
+        }
+        if (do_relu) {
+          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+        }
+        u32x2 o;
+        o.x = pack2bf(v0, v1);
+        o.y = pack2bf(v2, v3);
+        *reinterpret_cast<u32x2*>(optr) = o;
+        if (EPI != EPI_INFER && p.stats) {
+          const uint32_t w[2] = {o.x, o.y};
+          if constexpr (BSTATS) {
+            const u32x2 yq = *reinterpret_cast<const u32x2*>(p.stats_y + obase + co0);
+            const uint32_t yw[2] = {yq.x, yq.y};
+            const uint32_t sb = p.stats_mask
+                ? (uint32_t)p.stats_mask[opix * (p.ldc >> 3) + (co0 >> 3)] >> (co0 & 4) : 0xffu;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const float lo = (sb >> (2 * j)) & 1u ? __uint_as_float(w[j] << 16) : 0.f;
+              const float hi = (sb >> (2 * j + 1)) & 1u ? __uint_as_float(w[j] & 0xffff0000u) : 0.f;
+              st[2 * j] += lo;
+              st[2 * j + 1] += hi;
+              st[CPL + 2 * j] += lo * __uint_as_float(yw[j] << 16);
+              st[CPL + 2 * j + 1] += hi * __uint_as_float(yw[j] & 0xffff0000u);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+              st[2 * j] += lo;
+              st[2 * j + 1] += hi;
+              st[CPL + 2 * j] += lo * lo;
+              st[CPL + 2 * j + 1] += hi * hi;
+            }
+          }
+        }
+      } else {
+        const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (co0 + c < p.Cout) {
+            float x = vv[c];
+            if (aptr) x += bf2f(aptr[c]);
+            optr[c] = f2bf(do_relu ? fmaxf(x, 0.f) : x);
+          }
+        }
+      }
+    }
+  }
+  if (EPI != EPI_INFER && p.stats) {
+    constexpr int NV = 2 * CPL;
+    constexpr int HALVINGS = NV >= 16 ? 4 : 3;     // NV is 8, 16 or 32
+    constexpr int LEFT = NV >> HALVINGS;           // totals per lane afterwards
+    butterfly16<NV, NV, 0>(st, fr);
+    int base = 0;
+#pragma unroll
+    for (int t = 0; t < HALVINGS; ++t) base += ((fr >> t) & 1) * (NV >> (t + 1));
+    if (HALVINGS == 4 || (fr >> 3) == 0) {
+      float* dst = p.stats + (size_t)(mt % p.stats_replicas) * 2 * p.Cout;
+#pragma unroll
+      for (int j = 0; j < LEFT; ++j) {
+        const int idx = base + j;
+        const int q = idx / CPL, c = idx % CPL;    // quantity (sum / sum of squares), channel
+        if (co0 + c < p.Cout) atomicAdd(dst + q * p.Cout + co0 + c, st[j]);
+      }
+    }
+  }
+}
+
+}  // namespace conv_epi

@@ -69,8 +69,27 @@ __device__ __forceinline__ bf16x8 read_tr_frag(const uint8_t* tile, int c0, int 
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int BKK, int BCO, int WAVES_K, int WAVES_C, int G, bool POINTWISE>
-__global__ __launch_bounds__(64 * WAVES_K * WAVES_C * G, 4)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// waves per SIMD the register allocation must allow: what the LDS ring admits, at most 4
+constexpr int wgrad_occ(int bkk, int bco, int threads, int g, int stages) {
+  const int lds = g * stages * BP * (bkk + bco) * 2;
+  int bpc = (160 * 1024) / lds;
+  if (bpc < 1) bpc = 1;
+  const int w = bpc * threads / 256;
+  return w > 4 ? 4 : (w < 1 ? 1 : w);
+}
+
+// STAGES = 2: one reduction step in flight, drained (vmcnt(0)) at the barrier that ends every
+// step.  STAGES = 3, 4: the tiles of STAGES - 1 steps stay in flight; a wave waits with a counted
+// `s_waitcnt vmcnt(n)` for the step it is about to multiply and the block meets at a raw
+// `s_barrier`, which does not drain the vector-memory counter (same scheme as conv_pipe.hip).
+template <int BKK, int BCO, int WAVES_K, int WAVES_C, int G, bool POINTWISE, int STAGES>
+__global__ __launch_bounds__(64 * WAVES_K * WAVES_C * G,
+                             wgrad_occ(BKK, BCO, 64 * WAVES_K * WAVES_C * G, G, STAGES))
 void conv_wgrad_kernel(const WgradParams p) {
   constexpr int GT = 64 * WAVES_K * WAVES_C;                    // threads per wave group
   constexpr int WKK = BKK / WAVES_K, WCO = BCO / WAVES_C;
@@ -83,7 +102,14 @@ void conv_wgrad_kernel(const WgradParams p) {
   static_assert(GT * G <= 1024, "block size");
   static_assert(WKK % 16 == 0 && WCO % 16 == 0, "tile shape");
 
-  constexpr int GBYTES = 2 * (XBYTES + YBYTES);                 // LDS of one group
+  constexpr int SBYTES = XBYTES + YBYTES;                       // one stage of one group
+  constexpr int GBYTES = STAGES * SBYTES;                       // LDS of one group
+  // DMA instructions per wave and stage: identical for every wave when a pass fills at most
+  // BP rows (the counted waits of the deep pipeline rely on it)
+  constexpr int LPS = XV + YV;
+  static_assert(STAGES == 2 || (XRPP <= BP && YRPP <= BP && BP % XRPP == 0 && BP % YRPP == 0),
+                "deep pipeline needs the same number of loads in every wave");
+  static_assert(STAGES >= 2 && STAGES <= 4 && (STAGES - 1) * LPS < 64, "ring depth");
   // accumulator rows (index a) exchanged per round through the block's LDS
   constexpr int ACH = (G * GBYTES) / (CR * 16 * GT) < KR ? (G * GBYTES) / (CR * 16 * GT) : KR;
   static_assert(G == 1 || ACH >= 1, "accumulator exchange must fit in LDS");
@@ -135,8 +161,8 @@ void conv_wgrad_kernel(const WgradParams p) {
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
 
-  auto issue_tile = [&](int pstep, int buf) {
-    uint8_t* xs = smem + buf * (XBYTES + YBYTES);
+  auto issue_tile = [&](int pstep, int sbyte) {
+    uint8_t* xs = smem + sbyte;
     uint8_t* ys = xs + XBYTES;
 #pragma unroll
     for (int r = 0; r < XV; ++r) {
@@ -180,13 +206,8 @@ void conv_wgrad_kernel(const WgradParams p) {
   // group g takes reduction steps g, g + G, ...; the trip count is the same for every group
   // (a step past the end loads zeros) because all of them meet at the block barrier
   const int nsteps = ((pend - pbeg + BP - 1) / BP + G - 1) / G;
-  issue_tile(pbeg + grp * BP, 0);
-  __syncthreads();                                  // includes the vmcnt(0) wait for the DMA
-
-  for (int s = 0; s < nsteps; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nsteps) issue_tile(pbeg + ((s + 1) * G + grp) * BP, buf ^ 1);
-    const uint8_t* xs = smem + buf * (XBYTES + YBYTES);
+  auto multiply = [&](int sbyte) {
+    const uint8_t* xs = smem + sbyte;
     const uint8_t* ys = xs + XBYTES;
     bf16x8 xf[KR], yf[CR];
 #pragma unroll
@@ -198,7 +219,44 @@ void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int b = 0; b < CR; ++b)
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], yf[b], acc[a][b], 0, 0, 0);
+  };
+  if constexpr (STAGES == 2) {
+    issue_tile(pbeg + grp * BP, 0);
+    dma_wait_all();
     __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nsteps) issue_tile(pbeg + ((s + 1) * G + grp) * BP, (buf ^ 1) * SBYTES);
+      multiply(buf * SBYTES);
+      dma_wait_all();
+      __syncthreads();
+    }
+  } else {
+    int issue_byte = 0, read_byte = 0;
+    const int pre = nsteps < STAGES - 1 ? nsteps : STAGES - 1;
+    for (int s = 0; s < pre; ++s) {
+      issue_tile(pbeg + (s * G + grp) * BP, issue_byte);
+      issue_byte += SBYTES;
+    }
+    for (int s = 0; s < nsteps; ++s) {
+      // steps issued after s that may stay in flight while s is multiplied
+      const int ahead = (nsteps - 1 - s) < (STAGES - 2) ? (nsteps - 1 - s) : (STAGES - 2);
+      if (STAGES >= 4 && ahead >= 2) wait_vmcnt<(STAGES >= 4 ? 2 : 0) * LPS>();
+      else if (ahead >= 1) wait_vmcnt<LPS>();
+      else wait_vmcnt<0>();
+      // own LDS reads of the previous step retired, then the block meets: step s has landed for
+      // every wave and nobody still reads the buffer refilled next
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (s + STAGES - 1 < nsteps) {
+        issue_tile(pbeg + ((s + STAGES - 1) * G + grp) * BP, issue_byte);
+        issue_byte += SBYTES;
+        if (issue_byte == GBYTES) issue_byte = 0;
+      }
+      multiply(read_byte);
+      read_byte += SBYTES;
+      if (read_byte == GBYTES) read_byte = 0;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is reused below
   }
 
   // ---- groups 1..G-1 hand their accumulators to group 0 through LDS ------------------------
@@ -259,29 +317,45 @@ void conv_wgrad_kernel(const WgradParams p) {
   }
 }
 
-template <int BKK, int BCO, int WAVES_K, int WAVES_C, int G>
-void launch_grp(const WgradParams& p, hipStream_t stream) {
+template <int BKK, int BCO, int WAVES_K, int WAVES_C, int G, int STAGES>
+void launch_stg(const WgradParams& p, hipStream_t stream) {
   const int tilesK = (p.Ktotal + BKK - 1) / BKK;
   const int tilesC = (p.Cout + BCO - 1) / BCO;
   const bool pointwise = p.TI == 1 && p.TJ == 1 && p.ISH == 1 && p.ISW == 1 && p.dh0 == 0 &&
                          p.dw0 == 0 && p.OH == p.H && p.OW == p.W && p.Ctap <= p.Cpix;
   dim3 grid(tilesK * tilesC, p.splits);
   if (pointwise)
-    hipLaunchKernelGGL((conv_wgrad_kernel<BKK, BCO, WAVES_K, WAVES_C, G, true>), grid,
+    hipLaunchKernelGGL((conv_wgrad_kernel<BKK, BCO, WAVES_K, WAVES_C, G, true, STAGES>), grid,
                        dim3(64 * WAVES_K * WAVES_C * G), 0, stream, p);
   else
-    hipLaunchKernelGGL((conv_wgrad_kernel<BKK, BCO, WAVES_K, WAVES_C, G, false>), grid,
+    hipLaunchKernelGGL((conv_wgrad_kernel<BKK, BCO, WAVES_K, WAVES_C, G, false, STAGES>), grid,
                        dim3(64 * WAVES_K * WAVES_C * G), 0, stream, p);
 }
 
+template <int BKK, int BCO, int WAVES_K, int WAVES_C, int G>
+void launch_grp(const WgradParams& p, int stages, hipStream_t stream) {
+  // the deep pipeline exists for tiles whose every wave issues the same loads per step (all
+  // tiles at least 64 wide) and whose ring fits the LDS
+  constexpr int GT = 64 * WAVES_K * WAVES_C;
+  constexpr bool uniform = GT / (BKK / 8) <= BP && GT / (BCO / 8) <= BP;
+  if (stages == 2) return launch_stg<BKK, BCO, WAVES_K, WAVES_C, G, 2>(p, stream);
+  if constexpr (uniform && G * 3 * BP * (BKK + BCO) * 2 <= 160 * 1024) {
+    if (stages == 3) return launch_stg<BKK, BCO, WAVES_K, WAVES_C, G, 3>(p, stream);
+  }
+  if constexpr (uniform && G * 4 * BP * (BKK + BCO) * 2 <= 160 * 1024) {
+    if (stages == 4) return launch_stg<BKK, BCO, WAVES_K, WAVES_C, G, 4>(p, stream);
+  }
+  throw std::invalid_argument("conv_wgrad: this tile has no pipeline of that depth");
+}
+
 template <int BKK, int BCO, int WAVES_K, int WAVES_C>
-void launch_cfg(const WgradParams& p, int groups, hipStream_t stream) {
+void launch_cfg(const WgradParams& p, int groups, int stages, hipStream_t stream) {
   switch (groups) {
-    case 1: launch_grp<BKK, BCO, WAVES_K, WAVES_C, 1>(p, stream); break;
-    case 2: launch_grp<BKK, BCO, WAVES_K, WAVES_C, 2>(p, stream); break;
+    case 1: launch_grp<BKK, BCO, WAVES_K, WAVES_C, 1>(p, stages, stream); break;
+    case 2: launch_grp<BKK, BCO, WAVES_K, WAVES_C, 2>(p, stages, stream); break;
     case 4:
       if constexpr (WAVES_K * WAVES_C == 4) {
-        launch_grp<BKK, BCO, WAVES_K, WAVES_C, 4>(p, stream);
+        launch_grp<BKK, BCO, WAVES_K, WAVES_C, 4>(p, stages, stream);
         break;
       }
       [[fallthrough]];
@@ -314,22 +388,25 @@ void validate_wgrad_params(const WgradParams& p) {
   }
 }
 
-// cfg = tile id (0..15) + 16 * log2(groups): 1, 2 or 4 wave groups per block (tile 8, whose
-// groups have eight waves, allows 1 or 2).
+// cfg = tile id (0..15) + 16 * log2(groups) + 64 * (stages - 2): 1, 2 or 4 wave groups per block
+// (tile 8, whose groups have eight waves, allows 1 or 2); LDS ring of 2, 3 or 4 stages.
 void launch_conv_wgrad(const WgradParams& p, int cfg, hipStream_t stream) {
   validate_wgrad_params(p);
-  if (cfg < 0 || cfg >= 48) throw std::invalid_argument("conv_wgrad: unknown tile config");
+  if (cfg < 0 || cfg >= 192 || (cfg % 64) >= 48)
+    throw std::invalid_argument("conv_wgrad: unknown tile config");
+  const int stages = 2 + cfg / 64;
+  cfg %= 64;
   const int g = 1 << (cfg / 16);
   switch (cfg % 16) {
-    case 0: launch_cfg<128, 128, 2, 2>(p, g, stream); break;
-    case 1: launch_cfg<128, 64, 2, 2>(p, g, stream); break;
-    case 2: launch_cfg<64, 128, 2, 2>(p, g, stream); break;
-    case 3: launch_cfg<64, 64, 2, 2>(p, g, stream); break;
-    case 4: launch_cfg<128, 32, 4, 1>(p, g, stream); break;
-    case 5: launch_cfg<128, 16, 4, 1>(p, g, stream); break;
-    case 6: launch_cfg<32, 32, 2, 2>(p, g, stream); break;
-    case 7: launch_cfg<64, 16, 4, 1>(p, g, stream); break;
-    case 8: launch_cfg<256, 128, 4, 2>(p, g, stream); break;   // 8 waves: 96 FLOP per L2 byte
+    case 0: launch_cfg<128, 128, 2, 2>(p, g, stages, stream); break;
+    case 1: launch_cfg<128, 64, 2, 2>(p, g, stages, stream); break;
+    case 2: launch_cfg<64, 128, 2, 2>(p, g, stages, stream); break;
+    case 3: launch_cfg<64, 64, 2, 2>(p, g, stages, stream); break;
+    case 4: launch_cfg<128, 32, 4, 1>(p, g, stages, stream); break;
+    case 5: launch_cfg<128, 16, 4, 1>(p, g, stages, stream); break;
+    case 6: launch_cfg<32, 32, 2, 2>(p, g, stages, stream); break;
+    case 7: launch_cfg<64, 16, 4, 1>(p, g, stages, stream); break;
+    case 8: launch_cfg<256, 128, 4, 2>(p, g, stages, stream); break;   // 8 waves: 96 FLOP per L2 byte
     default: throw std::invalid_argument("conv_wgrad: unknown tile config");
   }
 }

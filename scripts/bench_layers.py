@@ -35,6 +35,10 @@ def main():
     if a.startswith("--fwd_cfg="): overrides["fwd"] = int(a.split("=")[1])
     if a.startswith("--wgrad_cfg="): overrides["wgrad"] = int(a.split("=")[1])
     if a.startswith("--splits="): overrides["splits"] = int(a.split("=")[1])
+    # --sweep_fwd=0,6,16,17: time forward and data gradient with each tile configuration and
+    # print the per-configuration times under the layer's row (best one marked)
+    if a.startswith("--sweep_wgrad="): overrides["sweep_w"] = [int(c) for c in a.split("=")[1].split(",")]
+    if a.startswith("--sweep_fwd="): overrides["sweep"] = [int(c) for c in a.split("=")[1].split(",")]
   spec = getattr(models, name)()
   dev = torch.device("cuda")
   shapes = collections.OrderedDict()
@@ -80,15 +84,48 @@ def main():
     if os.environ.get("DTF_WGRAD_PLAIN") == "1": wgd["debug_plain_store"] = 1
     t_w = timeit(lambda: native.run_op("wgrad", wgd))
     n = len(names)
+    sweep_txt = ""
+    if "sweep" in overrides:
+      rows = []
+      for c in overrides["sweep"]:
+        fd2 = dict(fd, cfg=c)
+        tf = timeit(lambda: native.run_op("conv", fd2), iters=10, warm=2)
+        td = 0.0
+        if not is_first:
+          dd2 = [dict(d, cfg=c) for d in dds]
+          td = timeit(lambda: [native.run_op("conv", d) for d in dd2], iters=10, warm=2)
+        rows.append((c, tf, td))
+      bf = min(rows, key=lambda r: r[1]); bd = min(rows, key=lambda r: r[2])
+      sweep_txt = "    sweep fwd: " + " ".join("%d:%.1f%s" % (c, tf, "*" if c == bf[0] else "") for c, tf, _ in rows)
+      sweep_txt += "\n    sweep dgrad: " + " ".join("%d:%.1f%s" % (c, td, "*" if c == bd[0] else "") for c, _, td in rows)
+      tot["fwd_best"] += n * min(bf[1], t_f); tot["dgrad_best"] += n * (min(bd[2], t_d) if t_d else 0)
     rf = max(2 * macs / PEAK_TF / 1e6, bytes_f / PEAK_GBS / 1e3)
     print("%-34s %3d %9.2f | %8.1f %7.1f %6.0f | %8.1f %7.1f | %8.1f %7.1f %4d | %6.1f" % (
         "%dx%dx%d k%d s%d ->%d c%d" % (h, w, c, k, stride, cout, fd["cfg"]), n, macs / 1e9,
         t_f, 2 * macs / t_f / 1e6, bytes_f / t_f / 1e3, t_d, (2 * macs / t_d / 1e6) if t_d else 0,
         t_w, 2 * macs / t_w / 1e6, wgd["splits"], rf))
+    if "sweep_w" in overrides:
+      rows = []
+      for c in overrides["sweep_w"]:
+        for sp in sorted({wgd["splits"], max(1, wgd["splits"] // 2), wgd["splits"] * 2}):
+          w2 = dict(wgd, cfg=c, splits=sp)
+          try:
+            rows.append((c, sp, timeit(lambda: native.run_op("wgrad", w2), iters=10, warm=2)))
+          except Exception:
+            pass
+      bw = min(rows, key=lambda r: r[2])
+      sweep_txt += ("\n" if sweep_txt else "") + "    sweep wgrad (cfg/splits:us): " + " ".join(
+          "%d/%d:%.1f%s" % (c, sp, t, "*" if (c, sp) == bw[:2] else "") for c, sp, t in rows)
+      tot["wgrad_best"] += n * min(bw[2], t_w)
+    if sweep_txt: print(sweep_txt, flush=True)
     tot["fwd"] += n * t_f; tot["dgrad"] += n * t_d; tot["wgrad"] += n * t_w
     floor["fwd"] += n * rf; floor["dgrad"] += n * (rf if t_d else 0); floor["wgrad"] += n * rf
   print("totals per step (ms): fwd %.2f dgrad %.2f wgrad %.2f  | roofline fwd %.2f dgrad %.2f wgrad %.2f" % (
       tot["fwd"] / 1e3, tot["dgrad"] / 1e3, tot["wgrad"] / 1e3, floor["fwd"] / 1e3, floor["dgrad"] / 1e3, floor["wgrad"] / 1e3))
+  if "sweep_w" in overrides:
+    print("best of sweep per layer (ms): wgrad %.2f" % (tot["wgrad_best"] / 1e3))
+  if "sweep" in overrides:
+    print("best of sweep per layer (ms): fwd %.2f dgrad %.2f" % (tot["fwd_best"] / 1e3, tot["dgrad_best"] / 1e3))
 
 
 if __name__ == "__main__":

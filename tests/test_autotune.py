@@ -45,8 +45,8 @@ def test_candidates_are_valid_configurations():
     for c in autotune._fwd_candidates(g.fwd(1, 2, 3)):
       assert c in conv_plan.FWD_CFGS
     for c, s in autotune._wgrad_candidates(g.wgrad(1, 2, 3)):
-      assert c % 16 in conv_plan.WGRAD_CFGS and c // 16 in (0, 1, 2) and s >= 1
-      assert not (c % 16 == 8 and c // 16 == 2)        # the 8-wave tile has at most 2 groups
+      assert c % 16 in conv_plan.WGRAD_CFGS and (c % 64) // 16 in (0, 1, 2) and c // 64 in (0, 1, 2) and s >= 1
+      assert not (c % 16 == 8 and (c % 64) // 16 == 2)        # the 8-wave tile has at most 2 groups
 
 
 def test_bundled_cache_is_well_formed():

@@ -101,11 +101,65 @@ def test_conv_fwd_dgrad_wgrad(case):
   assert err <= 0.01 * wr.grad.abs().max().item() + 1e-2, err
 
 
+PIPE_CFGS = list(range(16, 28))
+
+
+@pytest.mark.parametrize("cfg", PIPE_CFGS)
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, K, Cout, stride: shapes the multi-stage pipeline serves itself (pointwise,
+    # or channels per tap a multiple of the K-step), with ragged M / Cout / K and 1..72 K-steps
+    (3, 15, 13, 64, 1, 200, 1),        # one or two K-steps, ragged Cout and M
+    (2, 14, 14, 1024, 1, 256, 1),      # long K pointwise
+    (5, 9, 9, 72, 1, 136, 1),          # K = 72: ragged last K-step
+    (3, 15, 13, 64, 3, 64, 1),         # 3x3, out-of-image taps
+    (2, 16, 16, 128, 3, 128, 2),       # 3x3 stride 2 (TF SAME pad 0, 1); parity data gradients
+    (2, 16, 16, 256, 1, 512, 2),       # strided 1x1 projection (gather mode)
+    (4, 7, 7, 512, 3, 512, 1),         # K = 4608
+])
+def test_conv_pipeline_cfgs(case, cfg):
+  """Every tile configuration of the multi-stage kernel (conv_pipe.hip): forward, data gradient
+  and accumulate mode against fp32 PyTorch on the same bf16-rounded operands."""
+  native = _native()
+  N, H, W, Cin, K, Cout, stride = case
+  dev = torch.device("cuda")
+  gen = torch.Generator(device="cpu").manual_seed(sum(case) + cfg)
+  pad = same_padding(H, K, stride) + same_padding(W, K, stride)
+  g = ConvGeom(N, H, W, Cin, K, K, Cout, stride, pad)
+  x = _bf(torch.randn(N, H, W, Cin, generator=gen)).to(dev)
+  w = (torch.randn(K, K, Cin, Cout, generator=gen) * (1.0 / math.sqrt(K * K * Cin))).to(dev)
+  wq = _bf(w).float()
+  wf = _pack(native, g, w, "fwd")
+  out = torch.full(g.output_shape, float("nan"), dtype=torch.bfloat16, device=dev)
+  native.run_op("conv", g.fwd(x.data_ptr(), wf.data_ptr(), out.data_ptr(), cfg=cfg))
+  torch.cuda.synchronize()
+  ref = _ref_conv(x.float(), wq, stride, pad)
+  err = (out.float()[..., :Cout] - ref).abs().max().item()
+  assert err <= 0.02 * ref.abs().max().item() + 1e-2, err
+  dy = _bf(torch.randn(N, g.OH, g.OW, g.ldc, generator=gen)).to(dev)
+  dy[..., Cout:] = 0
+  xr = x.float().requires_grad_(True)
+  _ref_conv(xr, wq, stride, pad).backward(dy.float()[..., :Cout])
+  wd = _pack(native, g, w, "dgrad")
+  dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=dev)
+  for d in g.dgrad(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), cfg=cfg):
+    native.run_op("conv", d)
+  torch.cuda.synchronize()
+  err = (dx.float() - xr.grad).abs().max().item()
+  assert err <= 0.02 * xr.grad.abs().max().item() + 1e-2, err
+  dx2 = dx.clone()
+  for d in g.dgrad(dy.data_ptr(), wd.data_ptr(), dx2.data_ptr(), accumulate=True, cfg=cfg):
+    native.run_op("conv", d)
+  torch.cuda.synchronize()
+  assert torch.allclose(dx2.float(), 2 * dx.float(), rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("case", [
     # N, H, W, Cin, K, Cout, stride, cfg
     (4, 28, 28, 64, 3, 128, 1, 0), (4, 28, 28, 64, 1, 64, 1, 1), (3, 17, 17, 16, 3, 32, 1, 2),
     (3, 17, 17, 16, 3, 16, 2, 3), (2, 14, 14, 256, 1, 512, 1, 4), (4, 28, 28, 128, 1, 64, 1, 5),
-    (2, 9, 9, 32, 3, 72, 1, 0), (3, 28, 28, 64, 3, 128, 1, 6), (5, 14, 14, 256, 1, 200, 1, 6)])
+    (2, 9, 9, 32, 3, 72, 1, 0), (3, 28, 28, 64, 3, 128, 1, 6), (5, 14, 14, 256, 1, 200, 1, 6),
+    (3, 28, 28, 64, 3, 128, 1, 16), (5, 14, 14, 256, 1, 200, 1, 17), (4, 28, 28, 128, 1, 64, 1, 21),
+    (4, 28, 28, 64, 1, 64, 1, 23), (2, 14, 14, 256, 1, 512, 1, 25), (3, 28, 28, 64, 3, 128, 1, 20)])
 def test_conv_fused_bn_statistics(case):
   """The epilogue's per-channel sum / sum of squares equal those of the stored bf16 output,
   followed by the BatchNorm finalize that consumes the replicas."""
@@ -252,10 +306,15 @@ def test_conv_every_tile_config(cfg, shape):
 
 
 @pytest.mark.parametrize("cfg,splits", [(0, 5), (16, 3), (32, 2), (18, 4), (35, 1), (17, 7), (36, 2),
-                                        (22, 3), (39, 2), (8, 2), (24, 3)])
+                                        (22, 3), (39, 2), (8, 2), (24, 3),
+                                        # + 64 * (stages - 2): three- and four-stage LDS rings
+                                        (64, 5), (80, 3), (99, 1), (65, 7), (66, 4), (67, 2), (83, 3),
+                                        (72, 2), (88, 3), (128, 5), (144, 2), (129, 3), (131, 1),
+                                        (147, 2), (163, 2), (136, 1)])
 @pytest.mark.parametrize("shape", [(3, 19, 19, 64, 3, 136, 2), (2, 15, 15, 96, 1, 72, 1)])
 def test_wgrad_every_tile_config_and_group_count(cfg, splits, shape):
-  """Weight gradient under every tile / wave-group combination (cfg = tile + 16*log2(groups))."""
+  """Weight gradient under every tile / wave-group / pipeline-depth combination
+  (cfg = tile + 16 * log2(groups) + 64 * (stages - 2))."""
   native = _native()
   N, H, W, Cin, K, Cout, stride = shape
   dev = torch.device("cuda")
