@@ -256,7 +256,8 @@ void conv_wgrad_kernel(const WgradParams p) {
       read_byte += SBYTES;
       if (read_byte == GBYTES) read_byte = 0;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is reused below
+    if constexpr (G > 1)     // the accumulator exchange below reuses the ring
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 
   // ---- groups 1..G-1 hand their accumulators to group 0 through LDS ------------------------
@@ -274,7 +275,8 @@ void conv_wgrad_kernel(const WgradParams p) {
               for (int e = 0; e < 4; ++e)
                 red[(((a - a0) * CR + b) * 4 + e) * GT + tid] = acc[a][b][e];
         }
-        __syncthreads();
+        dma_wait_all();      // nothing is in flight here; keeps "no barrier without a wait"
+        __syncthreads();     // checkable for the whole kernel (tests/test_kernel_isa.py)
         if (grp == 0) {
 #pragma unroll
           for (int a = a0; a < a0 + ACH && a < KR; ++a)
@@ -284,6 +286,7 @@ void conv_wgrad_kernel(const WgradParams p) {
               for (int e = 0; e < 4; ++e)
                 acc[a][b][e] += red[(((a - a0) * CR + b) * 4 + e) * GT + tid];
         }
+        dma_wait_all();
         __syncthreads();
       }
     }

@@ -137,12 +137,12 @@ class GradientReducer:
     g = self._slice(b)
     c = self.comm
     self.bytes_reduced += g.numel() * 4
-    if g.is_cuda and c.backend != "nccl":
-      # gloo stages device tensors through the host on pool streams of its own.  With the
-      # default of four hardware queues per process those streams share a queue with the
-      # compute stream, and a step was seen to stall with kernels queued behind gloo's copies
-      # (it completes with GPU_MAX_HW_QUEUES=16).  gloo on GPU tensors is a test / rehearsal
-      # configuration, so the overlap is given up there: drain the compute stream first.
+    if g.is_cuda and c.backend != "nccl" and os.environ.get("DTF_GLOO_DRAIN", "1") != "0":
+      # gloo stages device tensors through the host on streams of its own; a rehearsal of
+      # several ranks on one GPU once stalled in this path.  The stall no longer reproduces with
+      # or without this drain (profiles/two_process_stall.md); gloo on device tensors is a
+      # test / rehearsal configuration, so the conservative order is kept: compute first, then
+      # the collective (DTF_GLOO_DRAIN=0 overlaps them).
       torch.cuda.current_stream(g.device).synchronize()
     cs = self._own_stream(g.device) if g.is_cuda else None
     if cs is not None:
