@@ -45,7 +45,12 @@ def main() -> int:
   ap.add_argument("--steps", type=int, default=30)
   ap.add_argument("--warmup", type=int, default=5)
   ap.add_argument("--batch", type=int, default=256, help="per-GPU batch size")
-  ap.add_argument("--model", default="resnet50", choices=["resnet50", "resnet56"])
+  ap.add_argument("--model", default="resnet50", choices=["resnet50", "resnet56", "resnet20"])
+  ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                  help="cpu: rehearsal of the launch / collective / reporting path without a GPU "
+                       "(gloo, PyTorch-operator executor, fp32); not a benchmark")
+  ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"],
+                  help="compute precision (default: bf16 on the GPU, fp32 on the CPU)")
   ap.add_argument("--num_packs", type=int, default=4, help="gradient fusion buckets")
   ap.add_argument("--all_reduce_alg", default=None)
   ap.add_argument("--no_graph", action="store_true")
@@ -81,31 +86,39 @@ def main() -> int:
                        "--nproc-per-node %d)\n" % (a.gpus, a.gpus))
       return 2
     a.gpus = world
-  if not torch.cuda.is_available():
-    sys.stderr.write("bench.py needs a GPU\n")
+  on_gpu = a.device == "cuda"
+  if on_gpu and not torch.cuda.is_available():
+    sys.stderr.write("bench.py needs a GPU (--device cpu rehearses the code path without one)\n")
     return 2
+  dtype = a.dtype or ("bf16" if on_gpu else "fp32")
+  if not on_gpu:
+    a.executor = "torch"
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // max(world, 1)))
 
   if a.gpus == 1 and a.rehearse_collectives:
     os.environ["DTF_REHEARSE_COLLECTIVES"] = "1"
   if a.gpus > 1 or a.rehearse_collectives:
-    strat = strategy_lib.MirroredStrategy(use_gpu=True, all_reduce_alg=a.all_reduce_alg,
+    strat = strategy_lib.MirroredStrategy(use_gpu=on_gpu, all_reduce_alg=a.all_reduce_alg,
                                           num_packs=a.num_packs)
     device = strat.device
     rank = strat.rank
   else:
     strat = None
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-    torch.cuda.set_device(device)
+    if on_gpu:
+      device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+      torch.cuda.set_device(device)
+    else:
+      device = torch.device("cpu")
     rank = 0
 
   if a.model == "resnet50":
     spec, shape, classes = models.resnet50(), (224, 224, 3), 1001
     loss, metric = "sparse_categorical_crossentropy", "sparse_categorical_accuracy"
   else:
-    spec, shape, classes = models.resnet56(), (32, 32, 3), 10
+    spec, shape, classes = getattr(models, a.model)(), (32, 32, 3), 10
     loss, metric = "sparse_categorical_crossentropy", "sparse_categorical_accuracy"
 
-  model = Model(spec, strategy=strat, dtype="bf16", device=device, executor=a.executor)
+  model = Model(spec, strategy=strat, dtype=dtype, device=device, executor=a.executor)
   from distributed_tensorflow_amd.train import schedules
   global_batch = a.batch * a.gpus
   if a.model == "resnet50":
@@ -124,7 +137,8 @@ def main() -> int:
   def sync():
     if strat is not None:
       strat.barrier()
-    torch.cuda.synchronize(device)
+    if on_gpu:
+      torch.cuda.synchronize(device)
 
   last = None
   # the executor times its first 8 steps to choose between hipGraph replay and eager launch;
@@ -153,13 +167,15 @@ def main() -> int:
     value = global_batch * a.steps / dt
     out = {
         "metric": ("images/sec (whole node) ResNet-50 ImageNet-224 bs256/GPU" if a.model == "resnet50"
-                   else "images/sec (whole node) ResNet-56 CIFAR-10 bs%d/GPU" % a.batch),
+                   else "images/sec (whole node) %s CIFAR-10 bs%d/GPU" % (
+                       {"resnet56": "ResNet-56", "resnet20": "ResNet-20"}[a.model], a.batch)),
         "value": round(value, 2), "unit": "images/sec", "n_gpus": a.gpus, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1000.0 * dt / a.steps, 3),
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": round(value / baseline_for(a.gpus), 3) if a.model == "resnet50" else None,
-        "dtype": "bf16",
-        "data": "synthetic (device-resident batch), random-init weights",
+        "dtype": dtype,
+        "data": "synthetic (device-resident batch), random-init weights" + (
+            "" if on_gpu else "; CPU rehearsal, not a benchmark"),
         "config": {"model": "resnet50_v1.5" if a.model == "resnet50" else a.model,
                    "global_batch": global_batch, "per_gpu_batch": a.batch,
                    "image": "%dx%dx%d" % shape, "classes": classes,

@@ -131,6 +131,44 @@ class RecordDataset(IterableDataset):
     return image, torch.from_numpy(np.asarray(label))
 
 
+class _Rebatcher:
+  """Iterable over the batches of a multi-worker `DataLoader` with batch boundaries restored.
+
+  `batch_size` and `drop_last` of a `DataLoader` over an `IterableDataset` apply *per worker*:
+  each worker ends its stream with a partial batch of its own.  Dropping those (drop_last)
+  loses up to `workers * (batch_size - 1)` samples per pass - enough to run an evaluation of
+  `num_images // batch_size` steps out of data - and keeping them yields short batches in the
+  middle of the stream.  The workers therefore never drop anything; full batches pass through
+  untouched and partial ones are merged here, so that only the very last batch of the whole
+  stream can be short (and is dropped when `drop_remainder` is set)."""
+
+  def __init__(self, loader, batch_size: int, drop_remainder: bool):
+    self.loader = loader
+    self.batch_size = int(batch_size)
+    self.drop_remainder = drop_remainder
+
+  def __iter__(self):
+    bs = self.batch_size
+    carry_x, carry_y, have = [], [], 0
+    for images, labels in self.loader:
+      n = int(images.shape[0])
+      if n == bs and not have:
+        yield images, labels
+        continue
+      carry_x.append(images)
+      carry_y.append(labels)
+      have += n
+      while have >= bs:
+        x = torch.cat(carry_x) if len(carry_x) > 1 else carry_x[0]
+        y = torch.cat(carry_y) if len(carry_y) > 1 else carry_y[0]
+        yield x[:bs], y[:bs]
+        have -= bs
+        carry_x, carry_y = ([x[bs:]], [y[bs:]]) if have else ([], [])
+    if have and not self.drop_remainder:
+      yield (torch.cat(carry_x) if len(carry_x) > 1 else carry_x[0],
+             torch.cat(carry_y) if len(carry_y) > 1 else carry_y[0])
+
+
 class DevicePrefetcher:
   """Copies batches to the device one step ahead on a side stream (final `prefetch`)."""
 
@@ -144,22 +182,10 @@ class DevicePrefetcher:
   def __len__(self):
     return len(self.loader)
 
-  def _start_workers(self):
-    """`iter(loader)`, which forks the worker processes.  The parent may hold GPU objects that
-    are only waiting for the garbage collector (executor plans, streams, events of an earlier
-    model); a collection inside a forked child would run their destructors there, and a HIP
-    call in a forked child aborts it.  So the parent collects first and freezes what is left
-    for the moment of the fork: the children inherit only permanent objects."""
-    import gc  # pylint: disable=import-outside-toplevel
-    gc.collect()
-    gc.freeze()
-    try:
-      return iter(self.loader)
-    finally:
-      gc.unfreeze()
-
   def __iter__(self):
-    it = self._start_workers()
+    # starts the worker processes; they come from a fork server that never touched the GPU
+    # (process_record_dataset), not from a fork of this process
+    it = iter(self.loader)
     if self.device.type != "cuda":
       for images, labels in it:
         yield images, labels
@@ -180,9 +206,16 @@ class DevicePrefetcher:
             lb = labels.to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(stream)
+          # The source may be a pinned staging buffer that its owner refills a few batches
+          # later (the native loaders hand out slots of a small ring): the copy must have
+          # read it before the next batch is requested.  This thread has nothing else to do
+          # meanwhile, and the consumer still only waits on the device side.
+          ev.synchronize()
           q.put((im, lb, ev))
-      finally:
-        q.put(None)
+      except BaseException as e:  # pylint: disable=broad-except
+        q.put(e)                  # decode errors, CRC mismatches, a dead worker: raised in the
+        return                    # consumer instead of looking like the end of the data
+      q.put(None)
 
     t = threading.Thread(target=producer, daemon=True)
     t.start()
@@ -191,6 +224,8 @@ class DevicePrefetcher:
         item = q.get()
         if item is None:
           return
+        if isinstance(item, BaseException):
+          raise RuntimeError("the input pipeline failed: %r" % (item,)) from item
         im, lb, ev = item
         torch.cuda.current_stream(self.device).wait_event(ev)
         im.record_stream(torch.cuda.current_stream(self.device))
@@ -218,10 +253,18 @@ def process_record_dataset(dataset: RecordDataset, is_training: bool, batch_size
   if workers > len(dataset.filenames) and not dataset.shard_records:
     dataset.shard_records = True
   pin = device is not None and torch.device(device).type == "cuda"
-  loader = DataLoader(dataset, batch_size=batch_size, drop_last=drop_remainder,
+  # Worker processes must not be forked from a process that has initialised the GPU (a HIP
+  # call, or a destructor of an inherited GPU object, aborts the child): they are started by a
+  # fork server, a helper process created from a clean interpreter that forks the workers on
+  # request.  CPU-only runs keep the plain fork (cheaper, nothing to inherit).
+  ctx = None
+  if workers and (pin or torch.cuda.is_initialized()):
+    ctx = os.environ.get("DTF_DATA_WORKER_START", "forkserver")
+  loader = DataLoader(dataset, batch_size=batch_size, drop_last=False,
                       num_workers=workers, pin_memory=pin,
                       prefetch_factor=(4 if tf_data_experimental_slack else 2) if workers else None,
-                      persistent_workers=False)
+                      persistent_workers=False, multiprocessing_context=ctx)
+  loader = _Rebatcher(loader, batch_size, drop_remainder)
   delay = float(os.environ.get("DTF_DATA_PREFETCH_DELAY_MS", "0"))
   pf = DevicePrefetcher(loader, device or torch.device("cpu"),
                         depth=3 if tf_data_experimental_slack else 2, delay_ms=delay)

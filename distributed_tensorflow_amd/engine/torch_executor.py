@@ -39,7 +39,15 @@ class TorchExecutor:
   native = False
 
   def __init__(self, spec: ModelSpec, store: ParamStore, batch_size: int,
-               dtype: str = "fp32", buckets: Optional[List[Bucket]] = None):
+               dtype: str = "fp32", buckets: Optional[List[Bucket]] = None,
+               data_format: str = "channels_last"):
+    """`data_format` is the memory layout of the activations (`resnet_model.py:243-251`
+    transposes to NCHW after the NHWC input layer for `channels_first`): logical tensors are
+    NCHW for the library ops either way, stored channel-major (`channels_first`) or
+    pixel-major (`channels_last`, torch's channels_last memory format)."""
+    if data_format not in ("channels_first", "channels_last"):
+      raise ValueError("data_format must be channels_first or channels_last")
+    self.data_format = data_format
     self.spec = spec
     self.store = store
     self.batch_size = batch_size
@@ -67,7 +75,9 @@ class TorchExecutor:
     x = images.to(self.device)
     if x.dim() != 4:
       raise ValueError("expected NHWC images, got shape %s" % (tuple(x.shape),))
-    t["input"] = x.permute(0, 3, 1, 2).to(dt)
+    x = x.permute(0, 3, 1, 2).to(dt)
+    t["input"] = x.contiguous() if self.data_format == "channels_first" else \
+        x.contiguous(memory_format=torch.channels_last)
     for op in self.spec.ops:
       a = op.attrs
       src = t[op.inputs[0]]

@@ -55,6 +55,7 @@ def init(use_gpu: Optional[bool] = None) -> Communicator:
 
 def shutdown():
   _state["comm"] = None
+  _state.pop("local_size", None)
   _comm_mod.shutdown()
 
 
@@ -81,8 +82,26 @@ def size() -> int:
 
 
 def local_size() -> int:
+  """Ranks of this job on this host (`hvd.local_size()`).
+
+  Launchers that spawn the ranks of a host export LOCAL_WORLD_SIZE; without it (ranks started
+  by hand from a TF_CONFIG, one per terminal or host) the ranks exchange their host names once
+  through the job's key-value store and count the matches."""
   import os  # pylint: disable=import-outside-toplevel
-  return int(os.environ.get("LOCAL_WORLD_SIZE", size()))
+  if "LOCAL_WORLD_SIZE" in os.environ:
+    return int(os.environ["LOCAL_WORLD_SIZE"])
+  if "local_size" not in _state:
+    c = _c()
+    if c.world_size <= 1:
+      _state["local_size"] = 1
+    else:
+      import socket  # pylint: disable=import-outside-toplevel
+      me = socket.gethostname()
+      store = c.store()
+      store.set("hvd/host/%d" % c.rank, me)
+      hosts = [store.get("hvd/host/%d" % r).decode() for r in range(c.world_size)]   # blocks
+      _state["local_size"] = sum(1 for h in hosts if h == me)
+  return _state["local_size"]
 
 
 def device() -> torch.device:

@@ -91,6 +91,13 @@ class Strategy:
     """Sums a small tensor of metric accumulators over the replicas."""
     return t
 
+  def average_state(self, state: torch.Tensor) -> torch.Tensor:
+    """Mean over the replicas of the non-trainable state (BatchNorm moving statistics), in
+    place.  Every replica normalises with its own batch statistics (no SyncBN, as in the
+    reference), so the moving averages drift apart; Keras declares them ON_READ / MEAN under
+    `MirroredStrategy`: reading them for a checkpoint or an export yields the replica mean."""
+    return state
+
   def barrier(self):
     pass
 
@@ -149,6 +156,11 @@ class MirroredStrategy(Strategy):
     if self.comm.world_size > 1 or self.comm.rehearse:
       self.comm.all_reduce(t)
     return t
+
+  def average_state(self, state):
+    if state.numel() and (self.comm.world_size > 1 or self.comm.rehearse):
+      self.comm.all_reduce(state, average=True)
+    return state
 
   def barrier(self):
     self.comm.barrier()

@@ -308,6 +308,12 @@ class ModelCheckpoint(Callback):
   """Saves the full model (weights + optimizer slots) after every epoch.
 
   `filepath` may contain `{epoch}` (1-based, as Keras formats it) and metric names.
+
+  Under a synchronous strategy with several replicas the callback has to be installed on every
+  replica: saving is collective there (the BatchNorm moving statistics written are the replica
+  mean, see `Model.save_replicated`) and only the chief writes the file.  The Horovod drivers run
+  without a strategy object and install it on rank 0 only, which saves rank 0's copy as the
+  reference does (`resnet_imagenet_main_horovod.py:258-259`).
   """
 
   def __init__(self, filepath, save_weights_only=False, verbose=0):
@@ -318,9 +324,6 @@ class ModelCheckpoint(Callback):
 
   def on_epoch_end(self, epoch, logs=None):
     path = self.filepath.format(epoch=epoch + 1, **(logs or {}))
-    if self.save_weights_only:
-      self.model.save_weights(path)
-    else:
-      self.model.save(path)
-    if self.verbose:
+    wrote = self.model.save_replicated(path, weights_only=self.save_weights_only)
+    if self.verbose and wrote:
       logging.info("Epoch %05d: saving model to %s", epoch + 1, path)

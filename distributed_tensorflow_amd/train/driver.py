@@ -79,9 +79,19 @@ def maybe_launch(flags_obj, argv) -> Optional[int]:
                              master_port=task.master_port, nnodes=len(tasks), node_rank=node)
   if ds == "parameter_server" and tfc is None:
     # Single command: 1 PS + (num_gpus - 1) workers on this node, one rank per GPU.
+    # N GPUs give 1 PS rank + (N - 1) worker ranks, one rank per GPU over RCCL.
     world = max(flags_obj.num_gpus, 2)
+    env_extra = {}
+    import torch  # pylint: disable=import-outside-toplevel
+    have = torch.cuda.device_count() if flags_obj.num_gpus > 0 else 0
+    if have < world and "DTF_BACKEND" not in os.environ:
+      # RCCL refuses two ranks on one GPU: with fewer GPUs than ranks (the minimum job is
+      # 1 PS + 1 worker) the ranks share devices and talk over gloo instead
+      logging.warning("parameter_server: %d ranks on %d GPU(s): ranks share devices, using the "
+                      "gloo backend (one rank per GPU is needed for RCCL)", world, have)
+      env_extra["DTF_BACKEND"] = "gloo"
     logging.info("parameter_server: launching 1 PS rank + %d worker ranks", world - 1)
-    return launch_lib.launch(argv, world, num_ps=1)
+    return launch_lib.launch(argv, world, num_ps=1, env_extra=env_extra or None)
   if n and tfc is None:
     logging.info("%s: launching %d ranks (one per GPU)", ds, n)
     return launch_lib.launch(argv, n)
@@ -286,10 +296,12 @@ def run_classifier(flags_obj, cfg: DatasetConfig, use_horovod: bool = False):
     eval_output = model.evaluate(eval_input_dataset, steps=num_eval_steps,
                                  verbose=2 if verbose else 0)
 
-  if flags_obj.export_dir and (strategy is None or strategy.is_chief) and not is_ps and \
-      (hvd is None or hvd.rank() == 0):
-    os.makedirs(flags_obj.export_dir, exist_ok=True)
-    model.save(os.path.join(flags_obj.export_dir, spec.name + ".h5"))
+  if flags_obj.export_dir and not is_ps and (hvd is None or hvd.rank() == 0):
+    # collective under a synchronous strategy (replica mean of the BatchNorm moving statistics);
+    # the chief writes
+    if strategy is None or strategy.is_chief:
+      os.makedirs(flags_obj.export_dir, exist_ok=True)
+    model.save_replicated(os.path.join(flags_obj.export_dir, spec.name + ".h5"))
 
   stats = common.build_stats(history, eval_output, callbacks)
   if strategy is not None:

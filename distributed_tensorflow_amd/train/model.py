@@ -31,6 +31,17 @@ from .optimizers import LossScaleOptimizer, Optimizer
 
 __all__ = ["Model", "SUPPORTED_LOSSES"]
 
+
+def _next_batch(it, what: str, step: int, steps: int):
+  """`next(it)` with an error that says what ran out (a bare StopIteration from inside `fit`
+  reads like a bug in the loop)."""
+  try:
+    return next(it)
+  except StopIteration:
+    raise RuntimeError("the %s input ran out of data at step %d of %d: the dataset holds fewer "
+                       "batches than steps were requested (repeat it, or lower the step count)"
+                       % (what, step, steps)) from None
+
 SUPPORTED_LOSSES = ("sparse_categorical_crossentropy", "categorical_crossentropy")
 
 
@@ -135,11 +146,16 @@ class Model:
         from ..engine.hip_executor import HipExecutor  # pylint: disable=import-outside-toplevel
         if self.dtype == "fp16":
           logging.warning("--dtype fp16: the native engine computes in bfloat16")
+        if self.data_format == "channels_first":
+          logging.warning("data_format channels_first has no effect on the native engine: its "
+                          "kernels are written for pixel-major (NHWC) activations; results do "
+                          "not depend on the layout")
         ex = HipExecutor(self.spec, self.store, batch, "bf16", self._bucket_list(),
                          use_graph=self.use_hip_graph,
                          fused_bn_stats=False if self.deterministic else None)
       else:
-        ex = TorchExecutor(self.spec, self.store, batch, self.dtype, self._bucket_list())
+        ex = TorchExecutor(self.spec, self.store, batch, self.dtype, self._bucket_list(),
+                           data_format=self.data_format)
       self._executors[batch] = ex
     return ex
 
@@ -261,16 +277,31 @@ class Model:
       t_epoch = time.time()
       if verbose:
         print("Epoch %d/%d" % (epoch + 1, epochs), flush=True)
+      # per-step results are kept as the tensors the step returned and folded into `acc` only
+      # when somebody looks (batch logs, progress line, end of epoch): three tiny device
+      # launches per step are a measurable share of a 2.5 ms step
+      pending: list = []
+
+      def fold():
+        by_n: Dict[int, list] = {}
+        for l, c, k in pending:
+          by_n.setdefault(k, []).append((l, c))
+        for k, items in by_n.items():
+          acc[0] += torch.stack([l for l, _ in items]).double().sum() * k
+          acc[1] += torch.stack([c for _, c in items]).double().sum()
+          acc[2] += k * len(items)
+        pending.clear()
+
       for step in range(steps_per_epoch):
         cbs.call("on_batch_begin", step, None)
-        images, labels = next(it)
+        images, labels = _next_batch(it, "training", epoch * steps_per_epoch + step,
+                                     epochs * steps_per_epoch)
         n = int(images.shape[0])
         loss, correct = self.train_on_batch(images, labels)
-        acc[0] += loss.double() * n
-        acc[1] += correct.double()
-        acc[2] += n
+        pending.append((loss, correct, n))
         logs = {"batch": step, "size": n}
         if cbs.wants_batch_logs or (verbose == 1 and self._progress_due(step, steps_per_epoch)):
+          fold()
           vals = acc.tolist()
           logs["loss"] = vals[0] / max(vals[2], 1)
           if self._acc_name:
@@ -278,8 +309,11 @@ class Model:
           if verbose == 1:
             self._print_progress(step, steps_per_epoch, logs, t_epoch)
         cbs.call("on_batch_end", step, logs)
+        if len(pending) >= 256:
+          fold()
         if self.stop_training:
           break
+      fold()
       logs = self._epoch_logs(acc)
       if validation_data is not None and (epoch + 1) % max(validation_freq, 1) == 0:
         val = self.evaluate(validation_data, steps=validation_steps, verbose=0)
@@ -333,8 +367,8 @@ class Model:
       steps = len(x)  # type: ignore[arg-type]
     acc = torch.zeros(3, dtype=torch.float64, device=self.device)
     it = iter(x)
-    for _ in range(steps):
-      images, labels = next(it)
+    for i in range(steps):
+      images, labels = _next_batch(it, "evaluation", i, steps)
       n = int(images.shape[0])
       loss, correct = self.test_on_batch(images, labels)
       acc[0] += loss.double() * n
@@ -376,6 +410,30 @@ class Model:
   def save(self, path: str, include_optimizer: bool = True):
     from ..checkpoint import keras_h5  # pylint: disable=import-outside-toplevel
     keras_h5.save_model(path, self, include_optimizer=include_optimizer)
+
+  def save_replicated(self, path: str, include_optimizer: bool = True,
+                      weights_only: bool = False) -> bool:
+    """Checkpoint of a model trained under a synchronous strategy.  COLLECTIVE: every replica
+    calls it.  The BatchNorm moving statistics written are the mean over the replicas (they are
+    per-replica quantities, aggregated MEAN on read in Keras' `MirroredStrategy`); the replicas'
+    own copies are left as they were.  Only the chief writes the file; returns True there."""
+    st = self.strategy
+    sync = st is not None and st.synchronous and st.num_replicas_in_sync > 1
+    chief = st is None or st.is_chief
+    keep = None
+    if sync:
+      keep = self.store.state.clone()
+      st.average_state(self.store.state)
+    try:
+      if chief:
+        if weights_only:
+          self.save_weights(path)
+        else:
+          self.save(path, include_optimizer)
+    finally:
+      if keep is not None:
+        self.store.state.copy_(keep)
+    return chief
 
   def load_weights(self, path: str, load_optimizer: bool = True):
     from ..checkpoint import keras_h5  # pylint: disable=import-outside-toplevel

@@ -387,8 +387,12 @@ def define_performance(num_parallel_calls=False, inter_op=True, intra_op=True,
 def define_image(data_format=True):
   if data_format:
     DEFINE_enum("data_format", None, ["channels_first", "channels_last"],
-                "Logical layout requested by the user. The native engine computes in "
-                "NHWC; channels_first inserts an explicit permute at the model input.", "df")
+                "Memory layout of the activations; inputs are NHWC either way, as in the "
+                "reference, and results do not depend on it.  The PyTorch-operator executor "
+                "stores activations channel-major (channels_first) or pixel-major "
+                "(channels_last).  The native MI355X engine is written for pixel-major "
+                "tensors only: it accepts channels_first with a warning and computes in NHWC.  "
+                "Default: channels_last.", "df")
 
 
 def define_benchmark(benchmark_log_dir=True, bigquery_uploader=True):

@@ -46,3 +46,26 @@ def test_bench_refuses_multi_gpu_without_launcher():
   r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
                      env=env, capture_output=True, text=True, timeout=300)
   assert r.returncode == 2 and "launcher" in r.stderr
+
+
+def test_bench_eight_ranks_under_torchrun_on_cpu():
+  """bench.py itself, launched exactly as the scaling run launches it (`torch.distributed.run`,
+  eight ranks, 127.0.0.1), rehearsed on the CPU: gloo collectives, PyTorch-operator executor,
+  a small model.  One JSON line from rank 0, `n_gpus` 8, whole-job rate over the global batch."""
+  env = dict(os.environ)
+  for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TF_CONFIG"):
+    env.pop(k, None)
+  env["OMP_NUM_THREADS"] = "1"
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+         "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"),
+         "--gpus", "8", "--steps", "2", "--warmup", "1", "--device", "cpu", "--model", "resnet20",
+         "--batch", "2"]
+  r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stderr[-3000:]
+  lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+  assert len(lines) == 1, r.stdout
+  out = json.loads(lines[0])
+  assert out["n_gpus"] == 8 and out["steps"] == 2 and out["warmup"] == 1
+  assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp8"
+  assert out["dtype"] == "fp32" and out["config"]["executor"] == "torch"
+  assert out["value"] == pytest.approx(16 * 1000.0 / out["ms_per_step"], rel=1e-2)

@@ -128,3 +128,29 @@ def test_stop_at_threshold_callback():
   assert not cb.model.stop_training
   cb.on_epoch_end(2, {"val_categorical_accuracy": 0.6})
   assert cb.model.stop_training
+
+
+def test_data_format_selects_the_activation_layout_not_the_result():
+  """`--data_format` is a layout choice (`resnet_model.py:243-251`): the PyTorch-operator
+  executor really stores activations channel-major or pixel-major, and the losses agree."""
+  import torch
+  from distributed_tensorflow_amd import models
+  from distributed_tensorflow_amd.train.model import Model
+  from distributed_tensorflow_amd.train.optimizers import SGD
+  runs = {}
+  for df in ("channels_first", "channels_last"):
+    m = Model(models.resnet20(), dtype="fp32", seed=1, data_format=df)
+    m.compile(SGD(0.1, momentum=0.9))
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4, 32, 32, 3, generator=g)
+    y = torch.randint(0, 10, (4, 1), generator=g).float()
+    losses = [m.train_on_batch(x, y)[0].item() for _ in range(3)]
+    ex = m._executor(4)
+    ex.debug_keep_activations = True
+    m.train_on_batch(x, y)
+    a = ex.last_activations["input"]
+    runs[df] = (losses, a.is_contiguous(), a.is_contiguous(memory_format=torch.channels_last))
+  assert runs["channels_first"][1] and not runs["channels_first"][2]
+  assert runs["channels_last"][2] and not runs["channels_last"][1]
+  for a, b in zip(runs["channels_first"][0], runs["channels_last"][0]):
+    assert abs(a - b) < 1e-3 * max(1.0, abs(a))

@@ -281,3 +281,57 @@ def test_imagenet_preprocess_shapes_and_mean_subtraction():
                                                   np.random.default_rng(0))
     assert out.shape == (224, 224, 3) and out.dtype == np.float32
     assert np.abs(out - want).max() < 3.0         # JPEG rounding of a flat colour
+
+
+def _line_reader(path):
+  with open(path, "rb") as f:
+    for line in f:
+      yield line.strip()
+
+
+def _line_parser(raw, is_training, dtype, rng=None):
+  v = int(raw)
+  return np.full((2, 2, 1), v, dtype=np.float32), np.array([v], dtype=np.float32)
+
+
+@pytest.mark.parametrize("workers", [0, 4])
+def test_batches_are_cut_after_merging_the_worker_streams(tmp_path, workers):
+  """47 records, batch 8, 4 workers: 5 full batches come out (47 // 8), every record at most
+  once - not the 4 batches left when each worker drops its own remainder - and asking for
+  more steps than there is data is a descriptive error, not a bare StopIteration."""
+  from distributed_tensorflow_amd.data import pipeline
+  files = []
+  n = 0
+  for i in range(4):
+    p = tmp_path / ("part-%d" % i)
+    cnt = 12 if i < 3 else 11
+    p.write_text("".join("%d\n" % (n + j) for j in range(cnt)))
+    n += cnt
+    files.append(str(p))
+  assert n == 47
+  ds = pipeline.RecordDataset(files, _line_reader, _line_parser, is_training=False,
+                              shuffle_buffer=0, num_epochs=1)
+  it = pipeline.process_record_dataset(ds, False, 8, device=None,
+                                       datasets_num_private_threads=workers, drop_remainder=True)
+  batches = list(it)
+  assert len(batches) == 47 // 8
+  assert all(tuple(x.shape) == (8, 2, 2, 1) for x, _ in batches)
+  seen = torch.cat([y.reshape(-1) for _, y in batches]).tolist()
+  assert len(set(seen)) == len(seen) == 40
+  # without drop_remainder the tail arrives as one short batch
+  ds2 = pipeline.RecordDataset(files, _line_reader, _line_parser, is_training=False,
+                               shuffle_buffer=0, num_epochs=1)
+  sizes = [int(x.shape[0]) for x, _ in pipeline.process_record_dataset(
+      ds2, False, 8, device=None, datasets_num_private_threads=workers, drop_remainder=False)]
+  assert sizes == [8] * 5 + [7]
+
+
+def test_evaluate_reports_exhausted_input():
+  from distributed_tensorflow_amd import models
+  from distributed_tensorflow_amd.train.model import Model
+  from distributed_tensorflow_amd.train.optimizers import SGD
+  m = Model(models.resnet20(), dtype="fp32")
+  m.compile(SGD(0.1), "sparse_categorical_crossentropy", ["sparse_categorical_accuracy"])
+  data = [(torch.zeros(2, 32, 32, 3), torch.zeros(2, 1))] * 2
+  with pytest.raises(RuntimeError, match="ran out of data at step 2 of 3"):
+    m.evaluate(data, steps=3)

@@ -151,6 +151,44 @@ strat.barrier()
   assert len({r["state"] for r in res}) > 1
 
 
+def test_checkpoint_under_mirrored_holds_replica_mean_of_moving_statistics(tmp_path):
+  """Saving under a synchronous strategy is collective: the chief's file carries the mean over
+  the replicas of the BatchNorm moving statistics (Keras ON_READ / MEAN aggregation), every
+  replica keeps its own copy, and only the chief writes."""
+  body = COMMON + """
+from distributed_tensorflow_amd.train.callbacks import ModelCheckpoint
+strat = S.get_distribution_strategy("mirrored", num_gpus=0, all_reduce_alg=None, num_packs=2)
+m = Model(models.resnet20(), strategy=strat, dtype="fp32", seed=0)
+m.compile(SGD(0.05, momentum=0.9), "sparse_categorical_crossentropy", ["sparse_categorical_accuracy"])
+g2 = torch.Generator().manual_seed(77 + rank)
+xs = torch.randn(4, 32, 32, 3, generator=g2) * (30 + 40 * rank) + 100
+ys = torch.randint(0, 10, (4, 1), generator=g2).float()
+for _ in range(2):
+  m.train_on_batch(xs, ys)
+mine = m.store.state.clone()
+path = os.path.join(os.environ["DTF_TEST_OUT"], "ck-{epoch}.h5")
+cb = ModelCheckpoint(path); cb.set_model(m)
+cb.on_epoch_end(0, {})
+assert torch.equal(m.store.state, mine)                 # the replica's own copy is untouched
+mean = mine.clone(); strat.average_state(mean)
+out = {"mine": mine.double().sum().item(), "mean": mean.double().sum().item(),
+       "wrote": os.path.exists(path.format(epoch=1))}
+if rank == 0:
+  m2 = Model(models.resnet20(), dtype="fp32", seed=5)
+  m2.compile(SGD(0.05, momentum=0.9), "sparse_categorical_crossentropy")
+  m2.load_weights(path.format(epoch=1))
+  out["loaded_equals_mean"] = bool(torch.allclose(m2.store.state, mean, rtol=0, atol=1e-6))
+  out["loaded_equals_mine"] = bool(torch.allclose(m2.store.state, mine, rtol=0, atol=1e-6))
+strat.barrier()
+save(out)
+"""
+  res = _run_ranks(tmp_path, body, 2)
+  assert res[0]["mine"] != res[1]["mine"]
+  assert res[0]["mean"] == pytest.approx(res[1]["mean"], rel=1e-9)
+  assert res[0]["loaded_equals_mean"] and not res[0]["loaded_equals_mine"]
+  assert len([f for f in os.listdir(tmp_path) if f.endswith(".h5")]) == 1
+
+
 def test_deterministic_replica_gradient_check(tmp_path):
   """`deterministic=True` compares gradient checksums across replicas after the all-reduce
   and raises when a replica's buffer was tampered with."""
@@ -224,6 +262,9 @@ def test_horovod_api(tmp_path):
 from distributed_tensorflow_amd import hvd
 hvd.init(use_gpu=False)
 assert hvd.size() == world and hvd.rank() == rank and hvd.local_rank() == rank
+assert hvd.local_size() == world                       # from the launcher's LOCAL_WORLD_SIZE
+del os.environ["LOCAL_WORLD_SIZE"]; hvd._state.pop("local_size", None)
+assert hvd.local_size() == world                       # counted from the ranks' host names
 t = torch.full((4,), float(rank + 1))
 avg = hvd.allreduce(t); tot = hvd.allreduce(t, average=False)
 b = hvd.broadcast(torch.full((2,), float(rank + 7)), root_rank=1)

@@ -133,3 +133,44 @@ def test_torch_executor_bn_semantics_and_learning():
   assert l.item() < l0.item() * 0.5
   p = ex.predict(x)
   assert p.shape == (8, 10) and torch.allclose(p.sum(1), torch.ones(8), atol=1e-5)
+
+
+@pytest.mark.parametrize("packs", [1, 4, 8])
+def test_gradient_buckets_complete_in_backward_order(packs):
+  """ResNet-50's fusion buckets are contiguous slices of the flat gradient buffer that fill up in
+  index order as the backward pass walks the layers in reverse: bucket k is complete before
+  any gradient of bucket k + 1 is written, so its all-reduce can start while the rest of the
+  backward pass runs (the overlap the multi-GPU step relies on)."""
+  import torch
+  from distributed_tensorflow_amd import models
+  from distributed_tensorflow_amd.engine.params import ParamStore
+  spec = models.resnet50()
+  store = ParamStore(spec, torch.device("cpu"), 0)
+  buckets = store.make_buckets(num_packs=packs)
+  assert len(buckets) >= packs
+  owner = {}
+  for b in buckets:
+    for v in b.var_names:
+      owner[v] = b.index
+  # contiguous cover of the gradient buffer, from its tail (last layers) to its head
+  assert buckets[0].end == store.num_elements and buckets[-1].start == 0
+  for a, b in zip(buckets, buckets[1:]):
+    assert b.end == a.start
+  # replay the backward pass: the variables of an op get their gradients when the op's backward
+  # runs, ops run in reverse execution order
+  remaining = {b.index: len(b.var_names) for b in buckets}
+  completed = []
+  started = set()
+  for op in reversed(spec.ops):
+    for suffix in ("kernel", "bias", "gamma", "beta"):
+      name = op.name + "/" + suffix
+      if name in owner:
+        k = owner[name]
+        # a bucket is only written once every earlier bucket is complete
+        assert all(remaining[j] == 0 for j in range(k)), (name, k)
+        started.add(k)
+        remaining[k] -= 1
+        if remaining[k] == 0:
+          completed.append(k)
+  assert completed == list(range(len(buckets)))
+  assert set(owner) == {e.spec.name for e in store.trainable}
