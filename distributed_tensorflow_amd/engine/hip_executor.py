@@ -58,6 +58,28 @@ def supports(spec: ModelSpec) -> bool:
   return True
 
 
+class _TypedPlan:
+  """A native `Plan` whose every op description carries the executor's element type."""
+
+  def __init__(self, plan, dt: int):
+    self._plan = plan
+    self._dt = dt
+
+  def add(self, kind, desc, name="", lane=0):
+    if self._dt and "dt" not in desc:
+      desc = dict(desc, dt=self._dt)
+    return self._plan.add(kind, desc, name, lane)
+
+  def __getattr__(self, item):
+    return getattr(self._plan, item)
+
+
+# element types of the native engine: name -> (code passed to the kernels, torch dtype)
+ELEMENT_TYPES = {"bf16": (0, torch.bfloat16), "bfloat16": (0, torch.bfloat16),
+                 "fp16": (1, torch.float16), "float16": (1, torch.float16),
+                 "fp32": (2, torch.float32), "float32": (2, torch.float32)}
+
+
 class HipExecutor:
   native = True
   STATS_REPLICAS = 32     # rows of atomically accumulated BatchNorm sums per layer
@@ -73,8 +95,14 @@ class HipExecutor:
                fused_bn_stats: Optional[bool] = None):
     if store.device.type != "cuda":
       raise RuntimeError("HipExecutor needs a GPU device")
-    if dtype not in ("bf16", "bfloat16"):
-      raise ValueError("the native engine computes in bf16 (got %s)" % dtype)
+    if dtype not in ELEMENT_TYPES:
+      raise ValueError("the native engine stores activations as bf16, fp16 or fp32 (got %s)" % dtype)
+    # bf16 is the type the engine is tuned for (fused statistics, folded inference BatchNorm,
+    # multi-stage pipelines); fp16 (the reference's mixed precision, with loss scaling) and fp32
+    # (the reference's default precision, exact fp32 matrix instructions) run the same plan on
+    # the same kernels instantiated for their element type, without those fusions
+    self.dt, self.act_dtype = ELEMENT_TYPES[dtype]
+    self.esize = torch.empty((), dtype=self.act_dtype).element_size()
     if not supports(spec):
       raise ValueError("model %s contains ops without a native kernel" % spec.name)
     native.ext()   # raises if the extension is missing: no silent fallback on the GPU
@@ -97,7 +125,7 @@ class HipExecutor:
     # deterministic sweep
     if fused_bn_stats is None:
       fused_bn_stats = os.environ.get("DTF_BN_FUSED_STATS", "1") != "0"
-    self.fused_bn_stats = fused_bn_stats
+    self.fused_bn_stats = fused_bn_stats and self.dt == 0
     self.overlap_wgrad = os.environ.get("DTF_WGRAD_STREAM", "1") != "0"
     self.wgrad_group = int(os.environ.get("DTF_WGRAD_GROUP", "0"))   # 0: decided while planning
     self._wgrad_queue: List[Tuple[Dict, str]] = []
@@ -113,8 +141,10 @@ class HipExecutor:
   # ----------------------------------------------------------------------------------------
   # buffers
   # ----------------------------------------------------------------------------------------
-  def _alloc(self, shape, dtype=torch.bfloat16, zero=True) -> torch.Tensor:
-    t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+  def _alloc(self, shape, dtype=None, zero=True) -> torch.Tensor:
+    """A planned buffer; `dtype` None: an activation tensor in the executor's element type."""
+    t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype or self.act_dtype,
+                                               device=self.device)
     self._keep.append(t)
     return t
 
@@ -151,7 +181,7 @@ class HipExecutor:
     a = first_conv.attrs
     merged = a["cin"] <= 4 and a["kw"] <= 8 and a["stride"] % 2 == 0
     g0 = ConvGeom(N, H, W, a["cin"], a["kh"], a["kw"], a["cout"], a["stride"], tuple(a["pad"]),
-                  mode="merged" if merged else "normal")
+                  mode="merged" if merged else "normal", dt=self.dt)
     geoms[first_conv.name] = g0
     acts["input"] = self._alloc(g0.input_shape)
     self._pre = dict(N=N, H=H, W=W, Cin=C, pt=a["pad"][0] if merged else 0,
@@ -166,10 +196,10 @@ class HipExecutor:
         if op.name not in geoms:
           h, w, c = shapes[op.inputs[0]]
           geoms[op.name] = ConvGeom(N, h, w, c, at["kh"], at["kw"], at["cout"], at["stride"],
-                                    tuple(at["pad"]))
+                                    tuple(at["pad"]), dt=self.dt)
         acts[op.output] = self._alloc(geoms[op.name].output_shape)
       elif op.kind == "dense":
-        geoms[op.name] = ConvGeom(N, 1, 1, at["in_features"], 1, 1, at["out_features"])
+        geoms[op.name] = ConvGeom(N, 1, 1, at["in_features"], 1, 1, at["out_features"], dt=self.dt)
         acts[op.output] = self._alloc((N, geoms[op.name].ldc))
       elif op.kind in ("bn", "maxpool"):
         ho, wo, c = shapes[op.output]
@@ -268,9 +298,9 @@ class HipExecutor:
                            for b in bn_ops if b.name in self._bn_stats_off}
 
     ext = native.ext()
-    self.fwd_plan = ext.Plan()
-    self.eval_plan = ext.Plan()
-    self.bwd_plan = ext.Plan()
+    self.fwd_plan = _TypedPlan(ext.Plan(), self.dt)
+    self.eval_plan = _TypedPlan(ext.Plan(), self.dt)
+    self.bwd_plan = _TypedPlan(ext.Plan(), self.dt)
     self._build_forward(self.fwd_plan, training=True)
     self._build_forward(self.eval_plan, training=False)
     self._build_backward(consumers)
@@ -310,12 +340,13 @@ class HipExecutor:
     for d in descs:
       d["first_block"] = blk
       blk += native.pack_blocks(d)
-    self.packed = self._alloc((off,), torch.bfloat16)
+    self.packed = self._alloc((off,))
     raw = native.pack_desc_bytes(descs)
     self.pack_descs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
     self._keep.append(self.pack_descs)
     self._pack_args = dict(params=self.store.params.data_ptr(), packed=self.packed.data_ptr(),
-                           descs=self.pack_descs.data_ptr(), ndesc=len(descs), nblocks=blk)
+                           descs=self.pack_descs.data_ptr(), ndesc=len(descs), nblocks=blk,
+                           dt=self.dt)
 
   def _add(self, plan, kind: str, desc: Dict, name: str, lane: int = 0):
     """plan.add with the measured tile configuration of this shape, when one is known."""
@@ -347,10 +378,10 @@ class HipExecutor:
     self._wgrad_queue = []
 
   def _wf_ptr(self, name):
-    return self.packed.data_ptr() + 2 * self._wf[name]
+    return self.packed.data_ptr() + self.esize * self._wf[name]
 
   def _wd_ptr(self, name):
-    return self.packed.data_ptr() + 2 * self._wd[name]
+    return self.packed.data_ptr() + self.esize * self._wd[name]
 
   # ---- forward ---------------------------------------------------------------------------
   def _build_forward(self, plan, training: bool):
@@ -478,8 +509,8 @@ class HipExecutor:
     returns {BatchNorm name: op} of the folded layers."""
     import struct
     spec, acts = self.spec, self.acts
-    if os.environ.get("DTF_EVAL_FOLD_BN", "1") == "0":
-      return {}
+    if os.environ.get("DTF_EVAL_FOLD_BN", "1") == "0" or self.dt != 0:
+      return {}       # the folded epilogue exists for bfloat16 only
     consumers: Dict[str, int] = {}
     for op in spec.ops:
       for t in op.inputs:
@@ -589,7 +620,7 @@ class HipExecutor:
           or src.name not in self._bn_bwd_stats_off or cin % 8
           or cin != src.attrs["channels"]):
         return {}
-      if acts[xname].numel() * 2 > small:
+      if acts[xname].numel() * self.esize > small:
         return {}
       addr = self.bn_stats.data_ptr() + 4 * self._bn_bwd_stats_off[src.name]
       self._bn_pre_stats[src.name] = addr
@@ -734,7 +765,7 @@ class HipExecutor:
                         op.name + "/wgrad")
         if (op is not first_conv and g.has_empty_parities() and defer_ok
             and uses_left.get(xname, 0) > 1 and xname not in written and xname not in pending
-            and acts[xname].numel() * 2 > small):
+            and acts[xname].numel() * self.esize > small):
           # A strided projection shortcut reaches one output parity in four.  As the first
           # writer of the block input's gradient it would fill the other three with zeros,
           # which the main branch's data gradient then reads back to accumulate; deferred
@@ -968,7 +999,7 @@ class HipExecutor:
                           device=self.device)
       native.run_op("softmax_probs", dict(logits=logits.data_ptr(), probs=probs.data_ptr(),
                                           N=self.N, C=self.spec.num_classes,
-                                          ld=logits.shape[1]))
+                                          ld=logits.shape[1], dt=self.dt))
     return probs
 
   def synchronize(self):

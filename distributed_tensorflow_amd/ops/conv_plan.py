@@ -102,6 +102,7 @@ class ConvGeom:
   pad: Tuple[int, int, int, int] = (0, 0, 0, 0)     # top, bottom, left, right
   mode: str = "normal"                              # normal | merged
   out_pitch: Optional[int] = None                   # channel pitch of the output tensor
+  dt: int = 0                                       # element type: 0 bf16, 1 fp16, 2 fp32
 
   def __post_init__(self):
     pt, pb, pl, pr = self.pad
@@ -169,6 +170,8 @@ class ConvGeom:
     if stats is not None:
       d["stats"] = stats
       d["stats_replicas"] = stats_replicas
+    if self.dt:
+      d["dt"] = self.dt
     if self.mode == "merged":
       d.update(TI=self.KH, TJ=1, Ctap=32, dh0=0, dw0=0, wsi=32, wsj=32)
     else:
@@ -220,6 +223,8 @@ class ConvGeom:
         d["in"] = dy
         d["wgt"] = wd
         d["out"] = dx
+        if self.dt:
+          d["dt"] = self.dt
         d["addend"] = dx if accumulate else addend
         if addend is not None and addend_mask is not None:
           d["addend_mask"] = addend_mask
@@ -239,6 +244,8 @@ class ConvGeom:
     d["x"] = x
     d["dy"] = dy
     d["dw"] = dw
+    if self.dt:
+      d["dt"] = self.dt
     if self.mode == "merged":
       d.update(TI=self.KH, TJ=1, Ctap=32, dh0=0, dw0=0, Cpad=4, Creal=self.Cin, TJpad=8,
                TJreal=self.KW)
@@ -248,6 +255,8 @@ class ConvGeom:
                Creal=self.Cin, TJpad=self.KW, TJreal=self.KW)
       ktotal = self.KH * self.KW * self.Cs
     c, sp = pick_wgrad_cfg(ktotal, self.Cout, self.M)
+    if self.dt == 2 and c >= 32:
+      c, sp = c - 16, sp * 2        # fp32 tiles are twice the bytes: at most two wave groups
     d["cfg"] = c if cfg is None else cfg
     d["splits"] = sp if splits is None else splits
     return d

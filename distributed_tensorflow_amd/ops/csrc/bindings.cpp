@@ -49,10 +49,11 @@ T* ptr(const py::dict& d, const char* key, bool required = true) {
 
 ConvParams conv_from_dict(const py::dict& d) {
   ConvParams p;
-  p.in = ptr<const bf16_t>(d, "in");
-  p.wgt = ptr<const bf16_t>(d, "wgt");
-  p.out = ptr<bf16_t>(d, "out");
-  p.addend = ptr<const bf16_t>(d, "addend", false);
+  p.dt = get_or<int>(d, "dt", DT_BF16);
+  p.in = ptr<const void>(d, "in");
+  p.wgt = ptr<const void>(d, "wgt");
+  p.out = ptr<void>(d, "out");
+  p.addend = ptr<const void>(d, "addend", false);
   p.addend_mask = ptr<const uint8_t>(d, "addend_mask", false);
   p.bias = ptr<const float>(d, "bias", false);
   p.scale = ptr<const float>(d, "scale", false);
@@ -87,8 +88,9 @@ ConvParams conv_from_dict(const py::dict& d) {
 
 WgradParams wgrad_from_dict(const py::dict& d) {
   WgradParams p;
-  p.x = ptr<const bf16_t>(d, "x");
-  p.dy = ptr<const bf16_t>(d, "dy");
+  p.dt = get_or<int>(d, "dt", DT_BF16);
+  p.x = ptr<const void>(d, "x");
+  p.dy = ptr<const void>(d, "dy");
   p.dw = ptr<float>(d, "dw");
   p.N = get<int>(d, "N"); p.H = get<int>(d, "H"); p.W = get<int>(d, "W");
   p.Cpix = get<int>(d, "Cpix");
@@ -119,6 +121,8 @@ WgradParams wgrad_from_dict(const py::dict& d) {
 }
 
 Launch make_op(const std::string& kind, const py::dict& d) {
+  // element type of the activation tensors of the op: 0 bf16 (default), 1 fp16, 2 fp32
+  const int dt = get_or<int>(d, "dt", DT_BF16);
   if (kind == "conv") {
     const ConvParams p = conv_from_dict(d);
     const int cfg = get_or<int>(d, "cfg", 0);
@@ -130,8 +134,8 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     return [p, cfg](hipStream_t s) { launch_conv_wgrad(p, cfg, s); };
   }
   if (kind == "bn_fwd_train") {
-    auto y = ptr<const bf16_t>(d, "y"); auto res = ptr<const bf16_t>(d, "res", false);
-    auto z = ptr<bf16_t>(d, "z");
+    auto y = ptr<const void>(d, "y"); auto res = ptr<const void>(d, "res", false);
+    auto z = ptr<void>(d, "z");
     auto gamma = ptr<const float>(d, "gamma"); auto beta = ptr<const float>(d, "beta");
     auto mm = ptr<float>(d, "mm"); auto mv = ptr<float>(d, "mv");
     auto smean = ptr<float>(d, "save_mean"); auto sinv = ptr<float>(d, "save_invstd");
@@ -148,32 +152,32 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     const int apply = get_or<int>(d, "apply", 1);      // 0: statistics + finalize only
     return [=](hipStream_t s) {
       launch_bn_fwd_train(y, res, z, mask, gamma, beta, mm, mv, smean, sinv, scale, shift, ws,
-                          fused, P, C, eps, mom, relu, rscale, rshift, apply, s);
+                          fused, P, C, eps, mom, relu, rscale, rshift, apply, dt, s);
     };
   }
   if (kind == "bn_pool_fwd_train" || kind == "bn_pool_bwd") {
     const int N = get<int>(d, "N"), H = get<int>(d, "H"), W = get<int>(d, "W"), C = get<int>(d, "C");
     const int OH = get<int>(d, "OH"), OW = get<int>(d, "OW"), k = get<int>(d, "k");
     const int st = get<int>(d, "stride"), pt = get<int>(d, "pt"), pl = get<int>(d, "pl");
-    auto y = ptr<const bf16_t>(d, "y"); auto idx = ptr<uint8_t>(d, "idx");
+    auto y = ptr<const void>(d, "y"); auto idx = ptr<uint8_t>(d, "idx");
     auto gamma = ptr<const float>(d, "gamma"); auto ws = ptr<float>(d, "ws");
     auto smean = ptr<float>(d, "save_mean"); auto sinv = ptr<float>(d, "save_invstd");
     if (kind == "bn_pool_fwd_train") {
-      auto zp = ptr<bf16_t>(d, "zp"); auto beta = ptr<const float>(d, "beta");
+      auto zp = ptr<void>(d, "zp"); auto beta = ptr<const float>(d, "beta");
       auto mm = ptr<float>(d, "mm"); auto mv = ptr<float>(d, "mv");
       auto scale = ptr<float>(d, "scale"); auto shift = ptr<float>(d, "shift");
       const int fused = get_or<int>(d, "fused_replicas", 0);
       const float eps = get<float>(d, "eps"), mom = get<float>(d, "momentum");
       return [=](hipStream_t s) {
         launch_bn_pool_fwd_train(y, zp, idx, gamma, beta, mm, mv, smean, sinv, scale, shift, ws,
-                                 fused, N, H, W, C, OH, OW, k, st, pt, pl, eps, mom, s);
+                                 fused, N, H, W, C, OH, OW, k, st, pt, pl, eps, mom, dt, s);
       };
     }
-    auto dzp = ptr<const bf16_t>(d, "dzp"); auto dy = ptr<bf16_t>(d, "dy");
+    auto dzp = ptr<const void>(d, "dzp"); auto dy = ptr<void>(d, "dy");
     auto dgamma = ptr<float>(d, "dgamma"); auto dbeta = ptr<float>(d, "dbeta");
     return [=](hipStream_t s) {
       launch_bn_pool_bwd(dzp, idx, y, smean, sinv, gamma, dgamma, dbeta, dy, ws, N, H, W, C, OH, OW,
-                         k, st, pt, pl, s);
+                         k, st, pt, pl, dt, s);
     };
   }
   if (kind == "bn_fold") {
@@ -183,53 +187,53 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     return [=](hipStream_t s) { launch_bn_fold(params, state, out, descs, n, s); };
   }
   if (kind == "bn_infer") {
-    auto y = ptr<const bf16_t>(d, "y"); auto res = ptr<const bf16_t>(d, "res", false);
-    auto z = ptr<bf16_t>(d, "z");
+    auto y = ptr<const void>(d, "y"); auto res = ptr<const void>(d, "res", false);
+    auto z = ptr<void>(d, "z");
     auto gamma = ptr<const float>(d, "gamma"); auto beta = ptr<const float>(d, "beta");
     auto mm = ptr<const float>(d, "mm"); auto mv = ptr<const float>(d, "mv");
     const int P = get<int>(d, "P"), C = get<int>(d, "C");
     const float eps = get<float>(d, "eps");
     const int relu = get<int>(d, "relu");
-    return [=](hipStream_t s) { launch_bn_infer(y, res, z, gamma, beta, mm, mv, P, C, eps, relu, s); };
+    return [=](hipStream_t s) { launch_bn_infer(y, res, z, gamma, beta, mm, mv, P, C, eps, relu, dt, s); };
   }
   if (kind == "bn_bwd") {
-    auto dz = ptr<const bf16_t>(d, "dz"); auto y = ptr<const bf16_t>(d, "y");
-    auto z = ptr<const bf16_t>(d, "z", false);
+    auto dz = ptr<const void>(d, "dz"); auto y = ptr<const void>(d, "y");
+    auto z = ptr<const void>(d, "z", false);
     auto mask = ptr<const uint8_t>(d, "mask", false);
     auto mean = ptr<const float>(d, "mean"); auto inv = ptr<const float>(d, "invstd");
     auto gamma = ptr<const float>(d, "gamma");
     auto dgamma = ptr<float>(d, "dgamma"); auto dbeta = ptr<float>(d, "dbeta");
-    auto dy = ptr<bf16_t>(d, "dy"); auto dres = ptr<bf16_t>(d, "dres", false);
+    auto dy = ptr<void>(d, "dy"); auto dres = ptr<void>(d, "dres", false);
     auto ws = ptr<float>(d, "ws");
     const int P = get<int>(d, "P"), C = get<int>(d, "C");
     // > 0: `ws` already holds that many replica rows of [sum g | sum g*y] left by the data-
     // gradient launches that produced dz; the reduction sweep is skipped
     const int pre = get_or<int>(d, "pre_replicas", 0);
     return [=](hipStream_t s) {
-      launch_bn_bwd(dz, y, z, mask, mean, inv, gamma, dgamma, dbeta, dy, dres, ws, P, C, pre, s);
+      launch_bn_bwd(dz, y, z, mask, mean, inv, gamma, dgamma, dbeta, dy, dres, ws, P, C, pre, dt, s);
     };
   }
   if (kind == "bn_bwd_dual") {
-    auto dz = ptr<const bf16_t>(d, "dz"); auto mask = ptr<const uint8_t>(d, "mask");
+    auto dz = ptr<const void>(d, "dz"); auto mask = ptr<const uint8_t>(d, "mask");
     auto ws = ptr<float>(d, "ws"); auto ws2 = ptr<float>(d, "ws2");
     const int P = get<int>(d, "P"), C = get<int>(d, "C");
-    auto y1 = ptr<const bf16_t>(d, "y"); auto y2 = ptr<const bf16_t>(d, "y2");
+    auto y1 = ptr<const void>(d, "y"); auto y2 = ptr<const void>(d, "y2");
     auto m1 = ptr<const float>(d, "mean"); auto m2 = ptr<const float>(d, "mean2");
     auto i1 = ptr<const float>(d, "invstd"); auto i2 = ptr<const float>(d, "invstd2");
     auto g1 = ptr<const float>(d, "gamma"); auto g2 = ptr<const float>(d, "gamma2");
     auto dg1 = ptr<float>(d, "dgamma"); auto dg2 = ptr<float>(d, "dgamma2");
     auto db1 = ptr<float>(d, "dbeta"); auto db2 = ptr<float>(d, "dbeta2");
-    auto dy1 = ptr<bf16_t>(d, "dy"); auto dy2 = ptr<bf16_t>(d, "dy2");
+    auto dy1 = ptr<void>(d, "dy"); auto dy2 = ptr<void>(d, "dy2");
     return [=](hipStream_t s) {
       launch_bn_bwd_dual(dz, mask, P, C, ws, ws2, y1, m1, i1, g1, dg1, db1, dy1, y2, m2, i2, g2, dg2,
-                         db2, dy2, s);
+                         db2, dy2, dt, s);
     };
   }
   if (kind == "mask_apply") {
-    auto x = ptr<const bf16_t>(d, "x"); auto mask = ptr<const uint8_t>(d, "mask");
-    auto out = ptr<bf16_t>(d, "out");
+    auto x = ptr<const void>(d, "x"); auto mask = ptr<const uint8_t>(d, "mask");
+    auto out = ptr<void>(d, "out");
     const size_t n = get<size_t>(d, "n");
-    return [=](hipStream_t s) { launch_mask_apply(x, mask, out, n, s); };
+    return [=](hipStream_t s) { launch_mask_apply(x, mask, out, n, dt, s); };
   }
   if (kind == "maxpool_fwd" || kind == "maxpool_bwd") {
     const int N = get<int>(d, "N"), H = get<int>(d, "H"), W = get<int>(d, "W"), C = get<int>(d, "C");
@@ -237,40 +241,40 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     const int st = get<int>(d, "stride"), pt = get<int>(d, "pt"), pl = get<int>(d, "pl");
     auto idx = ptr<uint8_t>(d, "idx");
     if (kind == "maxpool_fwd") {
-      auto x = ptr<const bf16_t>(d, "x"); auto out = ptr<bf16_t>(d, "out");
-      return [=](hipStream_t s) { launch_maxpool_fwd(x, out, idx, N, H, W, C, OH, OW, k, st, pt, pl, s); };
+      auto x = ptr<const void>(d, "x"); auto out = ptr<void>(d, "out");
+      return [=](hipStream_t s) { launch_maxpool_fwd(x, out, idx, N, H, W, C, OH, OW, k, st, pt, pl, dt, s); };
     }
-    auto dy = ptr<const bf16_t>(d, "dy"); auto dx = ptr<bf16_t>(d, "dx");
-    return [=](hipStream_t s) { launch_maxpool_bwd(dy, idx, dx, N, H, W, C, OH, OW, k, st, pt, pl, s); };
+    auto dy = ptr<const void>(d, "dy"); auto dx = ptr<void>(d, "dx");
+    return [=](hipStream_t s) { launch_maxpool_bwd(dy, idx, dx, N, H, W, C, OH, OW, k, st, pt, pl, dt, s); };
   }
   if (kind == "mean_fwd") {
-    auto x = ptr<const bf16_t>(d, "x"); auto out = ptr<bf16_t>(d, "out");
+    auto x = ptr<const void>(d, "x"); auto out = ptr<void>(d, "out");
     const int N = get<int>(d, "N"), HW = get<int>(d, "HW"), C = get<int>(d, "C");
-    return [=](hipStream_t s) { launch_global_mean_fwd(x, out, N, HW, C, s); };
+    return [=](hipStream_t s) { launch_global_mean_fwd(x, out, N, HW, C, dt, s); };
   }
   if (kind == "mean_bwd") {
-    auto dy = ptr<const bf16_t>(d, "dy"); auto dx = ptr<bf16_t>(d, "dx");
+    auto dy = ptr<const void>(d, "dy"); auto dx = ptr<void>(d, "dx");
     const int N = get<int>(d, "N"), HW = get<int>(d, "HW"), C = get<int>(d, "C");
-    return [=](hipStream_t s) { launch_global_mean_bwd(dy, dx, N, HW, C, s); };
+    return [=](hipStream_t s) { launch_global_mean_bwd(dy, dx, N, HW, C, dt, s); };
   }
   if (kind == "softmax_xent") {
-    auto logits = ptr<const bf16_t>(d, "logits"); auto labels = ptr<const int32_t>(d, "labels");
-    auto dl = ptr<bf16_t>(d, "dlogits", false); auto acc = ptr<float>(d, "accum");
+    auto logits = ptr<const void>(d, "logits"); auto labels = ptr<const int32_t>(d, "labels");
+    auto dl = ptr<void>(d, "dlogits", false); auto acc = ptr<float>(d, "accum");
     const int N = get<int>(d, "N"), C = get<int>(d, "C"), ld = get<int>(d, "ld");
     // grad_scale may change per step (dynamic loss scale): an optional device scalar carries it.
     const float gs = get_or<float>(d, "grad_scale", 1.f);
     auto gsd = ptr<const float>(d, "grad_scale_dev", false);   // multiplies grad_scale
-    return [=](hipStream_t s) { launch_softmax_xent(logits, labels, dl, acc, N, C, ld, gs, gsd, s); };
+    return [=](hipStream_t s) { launch_softmax_xent(logits, labels, dl, acc, N, C, ld, gs, gsd, dt, s); };
   }
   if (kind == "softmax_probs") {
-    auto logits = ptr<const bf16_t>(d, "logits"); auto probs = ptr<float>(d, "probs");
+    auto logits = ptr<const void>(d, "logits"); auto probs = ptr<float>(d, "probs");
     const int N = get<int>(d, "N"), C = get<int>(d, "C"), ld = get<int>(d, "ld");
-    return [=](hipStream_t s) { launch_softmax_probs(logits, probs, N, C, ld, s); };
+    return [=](hipStream_t s) { launch_softmax_probs(logits, probs, N, C, ld, dt, s); };
   }
   if (kind == "colsum") {
-    auto x = ptr<const bf16_t>(d, "x"); auto out = ptr<float>(d, "out");
+    auto x = ptr<const void>(d, "x"); auto out = ptr<float>(d, "out");
     const int N = get<int>(d, "N"), C = get<int>(d, "C"), ld = get<int>(d, "ld");
-    return [=](hipStream_t s) { launch_colsum(x, out, N, C, ld, s); };
+    return [=](hipStream_t s) { launch_colsum(x, out, N, C, ld, dt, s); };
   }
   if (kind == "sgd") {
     auto p = ptr<float>(d, "p"); auto g = ptr<const float>(d, "g"); auto v = ptr<float>(d, "v");
@@ -283,22 +287,22 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     return [=](hipStream_t s) { launch_sgd_momentum_l2(p, g, v, l2, n, lr, mom, gs, um, hyper, s); };
   }
   if (kind == "pack_weights") {
-    auto params = ptr<const float>(d, "params"); auto packed = ptr<bf16_t>(d, "packed");
+    auto params = ptr<const float>(d, "params"); auto packed = ptr<void>(d, "packed");
     auto descs = ptr<const PackDesc>(d, "descs");
     const int nd = get<int>(d, "ndesc"), nb = get<int>(d, "nblocks");
-    return [=](hipStream_t s) { launch_pack_weights(params, packed, descs, nd, nb, s); };
+    return [=](hipStream_t s) { launch_pack_weights(params, packed, descs, nd, nb, dt, s); };
   }
   if (kind == "preprocess_pad") {
-    auto in = ptr<const float>(d, "in"); auto out = ptr<bf16_t>(d, "out");
+    auto in = ptr<const float>(d, "in"); auto out = ptr<void>(d, "out");
     const int N = get<int>(d, "N"), H = get<int>(d, "H"), W = get<int>(d, "W");
     const int Cin = get<int>(d, "Cin"), pt = get<int>(d, "pt"), pl = get<int>(d, "pl");
     const int OH = get<int>(d, "OH"), OW = get<int>(d, "OW"), Cpad = get<int>(d, "Cpad");
-    return [=](hipStream_t s) { launch_preprocess_pad(in, out, N, H, W, Cin, pt, pl, OH, OW, Cpad, s); };
+    return [=](hipStream_t s) { launch_preprocess_pad(in, out, N, H, W, Cin, pt, pl, OH, OW, Cpad, dt, s); };
   }
-  if (kind == "cast_bf16") {
-    auto in = ptr<const float>(d, "in"); auto out = ptr<bf16_t>(d, "out");
+  if (kind == "cast_bf16" || kind == "cast") {      // fp32 -> the element type `dt`
+    auto in = ptr<const float>(d, "in"); auto out = ptr<void>(d, "out");
     const size_t n = get<size_t>(d, "n");
-    return [=](hipStream_t s) { launch_cast_f32_bf16(in, out, n, s); };
+    return [=](hipStream_t s) { launch_cast_from_f32(in, out, n, dt, s); };
   }
   if (kind == "memset") {
     auto p = ptr<uint8_t>(d, "ptr");

@@ -1,4 +1,4 @@
-// Fused BatchNorm kernels for NHWC bf16 activations (training forward / backward, inference).
+// Fused BatchNorm kernels for NHWC activations (bf16 / fp16 / fp32 storage, template DT) (training forward / backward, inference).
 //
 // Training forward is   z = relu?( gamma * (y - mean) * invstd + beta (+ residual) )
 // with per-channel batch statistics over all P = N*H*W pixels, computed in fp32 from the
@@ -99,7 +99,8 @@ __device__ __forceinline__ void block_reduce_to_partials(float (&part)[NV], int 
   }
 }
 
-__global__ __launch_bounds__(TPB) void bn_stats_kernel(const bf16_t* __restrict__ y,
+template <int DT>
+__global__ __launch_bounds__(TPB) void bn_stats_kernel(const void* __restrict__ y,
                                                        float* __restrict__ ws, int P, int C) {
   const int tpr = C >> 3, rpb = TPB / tpr;
   const int chunk = threadIdx.x % tpr, rowid = threadIdx.x / tpr;
@@ -109,14 +110,14 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const bf16_t* __restrict_
   const int stride = gridDim.x * rpb;
   int row = blockIdx.x * rpb + rowid;
   for (; row + 3 * stride < P; row += 4 * stride) {     // four independent 16-byte loads in flight
-    u32x4 v[4];
+    Raw8<DT> v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      v[u] = *reinterpret_cast<const u32x4*>(y + (size_t)(row + u * stride) * C + chunk * 8);
+      v[u] = ldraw<DT>(y, (size_t)(row + u * stride) * C + chunk * 8);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       float f[8];
-      unpack8(v[u], f);
+      unpack8<DT>(v[u], f);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         part[c] += f[c];
@@ -125,9 +126,9 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const bf16_t* __restrict_
     }
   }
   for (; row < P; row += stride) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(y + (size_t)row * C + chunk * 8);
+    const Raw8<DT> v = ldraw<DT>(y, (size_t)row * C + chunk * 8);
     float f[8];
-    unpack8(v, f);
+    unpack8<DT>(v, f);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       part[c] += f[c];
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(FIN_TPB) void bn_fwd_finalize_kernel(const BnFinali
 }
 
 struct BnApplyArgs {
-  const bf16_t* y; const bf16_t* res; bf16_t* z; uint8_t* mask;
+  const void* y; const void* res; void* z; uint8_t* mask;
   const float* scale; const float* shift;        // training: produced by the finalize kernel
   const float* gamma; const float* beta; const float* mm; const float* mv;   // inference
   int P, C; float eps; int relu;
@@ -236,7 +237,7 @@ __device__ __forceinline__ void fold_columns(const float* __restrict__ ws, int G
   __syncthreads();
 }
 
-template <bool FOLD>
+template <int DT, bool FOLD>
 __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
   const int C = a.C, tpr = C >> 3, rpb = TPB / tpr;
   const int chunk = threadIdx.x % tpr, rowid = threadIdx.x / tpr;
@@ -297,15 +298,15 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
   constexpr int U = 4;
   const int stride = gridDim.x * rpb;
   for (int row0 = blockIdx.x * rpb; row0 < a.P; row0 += U * stride) {
-    u32x4 yq[U], rq[U];
+    Raw8<DT> yq[U], rq[U];
     bool valid[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int row = row0 + u * stride + rowid;
       valid[u] = row < a.P;
       const size_t off = (size_t)row * C + chunk * 8;
-      yq[u] = valid[u] ? *reinterpret_cast<const u32x4*>(a.y + off) : u32x4{0, 0, 0, 0};
-      rq[u] = (valid[u] && a.res) ? *reinterpret_cast<const u32x4*>(a.res + off) : u32x4{0, 0, 0, 0};
+      yq[u] = valid[u] ? ldraw<DT>(a.y, off) : zero_raw<DT>();
+      rq[u] = (valid[u] && a.res) ? ldraw<DT>(a.res, off) : zero_raw<DT>();
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -314,12 +315,12 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
       float f[8];
       uint32_t bits = 0;
       if (valid[u]) {
-        unpack8(yq[u], f);
+        unpack8<DT>(yq[u], f);
 #pragma unroll
         for (int c = 0; c < 8; ++c) f[c] = f[c] * scale[c] + shift[c];
         if (a.res) {
           float r[8];
-          unpack8(rq[u], r);
+          unpack8<DT>(rq[u], r);
           if (raff) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) r[c] = r[c] * rsc[c] + rsh[c];
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
             f[c] = fmaxf(f[c], 0.f);
           }
         }
-        *reinterpret_cast<u32x4*>(a.z + off) = pack8(f);
+        straw<DT>(a.z, off, f);
       }
       if (a.relu && a.mask && prow0 < a.P) {         // block-uniform condition
         uint32_t w = bits << (8 * (threadIdx.x & 3));
@@ -348,12 +349,12 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
 }
 
 struct BnBwdArgs {
-  const bf16_t* dz; const bf16_t* y;
-  const bf16_t* z;          // forward output: ReLU mask = z > 0 (used when `mask` is null)
+  const void* dz; const void* y;
+  const void* z;          // forward output: ReLU mask = z > 0 (used when `mask` is null)
   const uint8_t* mask;      // bit mask written by the forward sweep; both null: no ReLU
   const float* mean; const float* invstd; const float* gamma;
   float* dgamma; float* dbeta;
-  bf16_t* dy; bf16_t* dres;
+  void* dy; void* dres;
   float* ws; int G;
   int P, C;
   int raw;                  // 1: `ws` rows hold [sum g | sum g*y] (from the data-gradient
@@ -361,11 +362,11 @@ struct BnBwdArgs {
   // Second BatchNorm fed by the same gradient (NB == 2 instantiations): the projection
   // shortcut's layer next to the block's last one.  Both see g = dz gated by the mask, so one
   // sweep reads dz and the mask once for the two of them.  No ReLU of its own, no dres.
-  const bf16_t* y2; const float* mean2; const float* invstd2; const float* gamma2;
-  float* dgamma2; float* dbeta2; bf16_t* dy2; float* ws2;
+  const void* y2; const float* mean2; const float* invstd2; const float* gamma2;
+  float* dgamma2; float* dbeta2; void* dy2; float* ws2;
 };
 
-template <int NB>
+template <int DT, int NB>
 __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
   const int C = a.C, tpr = C >> 3, rpb = TPB / tpr;
   const int chunk = threadIdx.x % tpr, rowid = threadIdx.x / tpr;
@@ -382,17 +383,17 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) part2[i] = 0.f;
   const int mode = a.mask ? 2 : (a.z ? 1 : 0);
-  auto accumulate = [&](const u32x4& gv, const u32x4& yq, const u32x4& zq, uint32_t bits,
-                        const u32x4& y2q) {
+  auto accumulate = [&](const Raw8<DT>& gv, const Raw8<DT>& yq, const Raw8<DT>& zq, uint32_t bits,
+                        const Raw8<DT>& y2q) {
     float g[8], yv[8];
-    unpack8(gv, g);
-    unpack8(yq, yv);
+    unpack8<DT>(gv, g);
+    unpack8<DT>(yq, yv);
     if (mode == 2) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) g[c] = (bits >> c) & 1u ? g[c] : 0.f;
     } else if (mode == 1) {
       float zv[8];
-      unpack8(zq, zv);
+      unpack8<DT>(zq, zv);
 #pragma unroll
       for (int c = 0; c < 8; ++c) g[c] = zv[c] > 0.f ? g[c] : 0.f;
     }
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
     }
     if constexpr (NB == 2) {
       float y2v[8];
-      unpack8(y2q, y2v);
+      unpack8<DT>(y2q, y2v);
 #pragma unroll
       for (int c = 0; c < 8; ++c) part2[c] += g[c] * ((y2v[c] - mean2[c]) * invstd2[c]);
     }
@@ -411,27 +412,27 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
   const int stride = gridDim.x * rpb;
   int row = blockIdx.x * rpb + rowid;
   for (; row + 3 * stride < a.P; row += 4 * stride) {      // four rows of loads in flight
-    u32x4 gv[4], yq[4], zq[4], y2q[4];
+    Raw8<DT> gv[4], yq[4], zq[4], y2q[4];
     uint32_t bits[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const size_t off = (size_t)(row + u * stride) * C + chunk * 8;
-      gv[u] = *reinterpret_cast<const u32x4*>(a.dz + off);
-      yq[u] = *reinterpret_cast<const u32x4*>(a.y + off);
-      zq[u] = mode == 1 ? *reinterpret_cast<const u32x4*>(a.z + off) : u32x4{0, 0, 0, 0};
+      gv[u] = ldraw<DT>(a.dz, off);
+      yq[u] = ldraw<DT>(a.y, off);
+      zq[u] = mode == 1 ? ldraw<DT>(a.z, off) : zero_raw<DT>();
       bits[u] = mode == 2 ? a.mask[(size_t)(row + u * stride) * tpr + chunk] : 0u;
-      y2q[u] = NB == 2 ? *reinterpret_cast<const u32x4*>(a.y2 + off) : u32x4{0, 0, 0, 0};
+      y2q[u] = NB == 2 ? ldraw<DT>(a.y2, off) : zero_raw<DT>();
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) accumulate(gv[u], yq[u], zq[u], bits[u], y2q[u]);
   }
   for (; row < a.P; row += stride) {
     const size_t off = (size_t)row * C + chunk * 8;
-    const u32x4 gv = *reinterpret_cast<const u32x4*>(a.dz + off);
-    const u32x4 yq = *reinterpret_cast<const u32x4*>(a.y + off);
-    const u32x4 zq = mode == 1 ? *reinterpret_cast<const u32x4*>(a.z + off) : u32x4{0, 0, 0, 0};
+    const Raw8<DT> gv = ldraw<DT>(a.dz, off);
+    const Raw8<DT> yq = ldraw<DT>(a.y, off);
+    const Raw8<DT> zq = mode == 1 ? ldraw<DT>(a.z, off) : zero_raw<DT>();
     const uint32_t bits = mode == 2 ? a.mask[(size_t)row * tpr + chunk] : 0u;
-    const u32x4 y2q = NB == 2 ? *reinterpret_cast<const u32x4*>(a.y2 + off) : u32x4{0, 0, 0, 0};
+    const Raw8<DT> y2q = NB == 2 ? ldraw<DT>(a.y2, off) : zero_raw<DT>();
     accumulate(gv, yq, zq, bits, y2q);
   }
   if constexpr (NB == 2) {
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(FIN_TPB) void bn_bwd_finalize_kernel(const BnBwdArg
 // FOLD: `ws` holds G replica rows of [sum g | sum g*y] (left by the data-gradient epilogues) of
 // a narrow layer; every block derives dbeta / dgamma itself (block 0 stores them into the
 // gradient buffer) instead of waiting for a finalize launch.
-template <bool FOLD, int NB = 1>
+template <int DT, bool FOLD, int NB = 1>
 __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   const int C = a.C, tpr = C >> 3, rpb = TPB / tpr;
   const int chunk = threadIdx.x % tpr, rowid = threadIdx.x / tpr;
@@ -518,79 +519,79 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
     }
   }
   const int mode = a.mask ? 2 : (a.z ? 1 : 0);
-  auto finish = [&](const u32x4& gv, const u32x4& yq, const u32x4& zq, uint32_t bits, size_t off,
-                    const u32x4& y2q) {
+  auto finish = [&](const Raw8<DT>& gv, const Raw8<DT>& yq, const Raw8<DT>& zq, uint32_t bits, size_t off,
+                    const Raw8<DT>& y2q) {
     float g[8], yv[8];
-    unpack8(gv, g);
-    unpack8(yq, yv);
+    unpack8<DT>(gv, g);
+    unpack8<DT>(yq, yv);
     if (mode == 2) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) g[c] = (bits >> c) & 1u ? g[c] : 0.f;
     } else if (mode == 1) {
       float zv[8];
-      unpack8(zq, zv);
+      unpack8<DT>(zq, zv);
 #pragma unroll
       for (int c = 0; c < 8; ++c) g[c] = zv[c] > 0.f ? g[c] : 0.f;
     }
-    if (a.dres) *reinterpret_cast<u32x4*>(a.dres + off) = pack8(g);
+    if (a.dres) straw<DT>(a.dres, off, g);
     float o[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const float xhat = (yv[c] - mean[c]) * invstd[c];
       o[c] = scale[c] * (g[c] - c1[c] - xhat * c2[c]);
     }
-    *reinterpret_cast<u32x4*>(a.dy + off) = pack8(o);
+    straw<DT>(a.dy, off, o);
     if constexpr (NB == 2) {
       float y2v[8], o2[8];
-      unpack8(y2q, y2v);
+      unpack8<DT>(y2q, y2v);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const float xhat = (y2v[c] - mean2[c]) * invstd2[c];
         o2[c] = scale2[c] * (g[c] - c12[c] - xhat * c22[c]);
       }
-      *reinterpret_cast<u32x4*>(a.dy2 + off) = pack8(o2);
+      straw<DT>(a.dy2, off, o2);
     }
   };
   const int stride = gridDim.x * rpb;
   int row = blockIdx.x * rpb + rowid;
   for (; row + 3 * stride < a.P; row += 4 * stride) {      // four rows of loads in flight
-    u32x4 gv[4], yq[4], zq[4], y2q[4];
+    Raw8<DT> gv[4], yq[4], zq[4], y2q[4];
     uint32_t bits[4];
     size_t off[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       off[u] = (size_t)(row + u * stride) * C + chunk * 8;
-      gv[u] = *reinterpret_cast<const u32x4*>(a.dz + off[u]);
-      yq[u] = *reinterpret_cast<const u32x4*>(a.y + off[u]);
-      zq[u] = mode == 1 ? *reinterpret_cast<const u32x4*>(a.z + off[u]) : u32x4{0, 0, 0, 0};
+      gv[u] = ldraw<DT>(a.dz, off[u]);
+      yq[u] = ldraw<DT>(a.y, off[u]);
+      zq[u] = mode == 1 ? ldraw<DT>(a.z, off[u]) : zero_raw<DT>();
       bits[u] = mode == 2 ? a.mask[(size_t)(row + u * stride) * tpr + chunk] : 0u;
-      y2q[u] = NB == 2 ? *reinterpret_cast<const u32x4*>(a.y2 + off[u]) : u32x4{0, 0, 0, 0};
+      y2q[u] = NB == 2 ? ldraw<DT>(a.y2, off[u]) : zero_raw<DT>();
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) finish(gv[u], yq[u], zq[u], bits[u], off[u], y2q[u]);
   }
   for (; row < a.P; row += stride) {
     const size_t off = (size_t)row * C + chunk * 8;
-    const u32x4 gv = *reinterpret_cast<const u32x4*>(a.dz + off);
-    const u32x4 yq = *reinterpret_cast<const u32x4*>(a.y + off);
-    const u32x4 zq = mode == 1 ? *reinterpret_cast<const u32x4*>(a.z + off) : u32x4{0, 0, 0, 0};
+    const Raw8<DT> gv = ldraw<DT>(a.dz, off);
+    const Raw8<DT> yq = ldraw<DT>(a.y, off);
+    const Raw8<DT> zq = mode == 1 ? ldraw<DT>(a.z, off) : zero_raw<DT>();
     const uint32_t bits = mode == 2 ? a.mask[(size_t)row * tpr + chunk] : 0u;
-    const u32x4 y2q = NB == 2 ? *reinterpret_cast<const u32x4*>(a.y2 + off) : u32x4{0, 0, 0, 0};
+    const Raw8<DT> y2q = NB == 2 ? ldraw<DT>(a.y2, off) : zero_raw<DT>();
     finish(gv, yq, zq, bits, off, y2q);
   }
 }
 
-__global__ __launch_bounds__(TPB) void mask_apply_kernel(const bf16_t* __restrict__ x,
+template <int DT>
+__global__ __launch_bounds__(TPB) void mask_apply_kernel(const void* __restrict__ x,
                                                          const uint8_t* __restrict__ mask,
-                                                         bf16_t* __restrict__ out, size_t nvec) {
+                                                         void* __restrict__ out, size_t nvec) {
   for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (size_t)gridDim.x * TPB) {
-    u32x4 v = *reinterpret_cast<const u32x4*>(x + i * 8);
+    float f[8];
+    unpack8<DT>(ldraw<DT>(x, i * 8), f);
     const uint32_t b = mask[i];
-    v.x &= ((b & 1u) ? 0xffffu : 0u) | ((b & 2u) ? 0xffff0000u : 0u);
-    v.y &= ((b & 4u) ? 0xffffu : 0u) | ((b & 8u) ? 0xffff0000u : 0u);
-    v.z &= ((b & 16u) ? 0xffffu : 0u) | ((b & 32u) ? 0xffff0000u : 0u);
-    v.w &= ((b & 64u) ? 0xffffu : 0u) | ((b & 128u) ? 0xffff0000u : 0u);
-    *reinterpret_cast<u32x4*>(out + i * 8) = v;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) f[c] = (b >> c) & 1u ? f[c] : 0.f;
+    straw<DT>(out, i * 8, f);
   }
 }
 
@@ -604,11 +605,11 @@ __global__ __launch_bounds__(TPB) void mask_apply_kernel(const bf16_t* __restric
 // BatchNorm backward sweeps, so the scattered gradient tensor is never materialised either.
 // Threads own a fixed 8-channel chunk (256 % (C/8) == 0), a block walks image rows.
 struct BnPoolArgs {
-  const bf16_t* y;             // [N,H,W,C] convolution output
-  bf16_t* zp;                  // [N,OH,OW,C] pooled activation (forward)
+  const void* y;             // [N,H,W,C] convolution output
+  void* zp;                  // [N,OH,OW,C] pooled activation (forward)
   uint8_t* idx;                // [N,OH,OW,C] winning tap / 255
-  const bf16_t* dzp;           // [N,OH,OW,C] gradient of the pooled activation (backward)
-  bf16_t* dy;                  // [N,H,W,C] gradient of the convolution output (backward)
+  const void* dzp;           // [N,OH,OW,C] gradient of the pooled activation (backward)
+  void* dy;                  // [N,H,W,C] gradient of the convolution output (backward)
   const float* scale; const float* shift;                    // forward
   const float* mean; const float* invstd; const float* gamma;
   const float* dgamma; const float* dbeta;                   // backward apply
@@ -616,6 +617,7 @@ struct BnPoolArgs {
   int N, H, W, C, OH, OW, k, stride, pt, pl;
 };
 
+template <int DT>
 __global__ __launch_bounds__(TPB) void bn_pool_fwd_kernel(const BnPoolArgs a) {
   const int C = a.C;
   const uint32_t cpr = (uint32_t)C >> 3;
@@ -639,8 +641,7 @@ __global__ __launch_bounds__(TPB) void bn_pool_fwd_kernel(const BnPoolArgs a) {
           const int wi = (int)ow * a.stride - a.pl + kw;
           if ((unsigned)wi >= (unsigned)a.W) continue;
           float f[8];
-          unpack8(*reinterpret_cast<const u32x4*>(
-                      a.y + ((size_t)(n * a.H + hi) * a.W + wi) * C + chunk * 8), f);
+          unpack8<DT>(ldraw<DT>(a.y, ((size_t)(n * a.H + hi) * a.W + wi) * C + chunk * 8), f);
           const uint32_t tap = (uint32_t)(kh * a.k + kw);
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(TPB) void bn_pool_fwd_kernel(const BnPoolArgs a) {
         }
       }
       const size_t o = ((size_t)row * a.OW + ow) * C + chunk * 8;
-      *reinterpret_cast<u32x4*>(a.zp + o) = pack8(best);
+      straw<DT>(a.zp, o, best);
       u32x2 pk;
       pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
       pk.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(TPB) void bn_pool_fwd_kernel(const BnPoolArgs a) {
 // kh0 + stride of the window before it.  The four candidate windows of an element are loaded
 // unconditionally (addresses clamped) before any is used, and accumulated under predicates.
 // S: compile-time stride (0 = read it from the arguments).
-template <bool APPLY, int S>
+template <int DT, bool APPLY, int S>
 __global__ __launch_bounds__(TPB) void bn_pool_bwd_kernel(const BnPoolArgs a) {
   const int C = a.C, k = a.k, stride = S ? S : a.stride;
   const uint32_t cpr = (uint32_t)C >> 3;
@@ -696,18 +697,18 @@ __global__ __launch_bounds__(TPB) void bn_pool_bwd_kernel(const BnPoolArgs a) {
     for (uint32_t j = threadIdx.x; j < per_row; j += TPB) {
       const int w = (int)(j / cpr);
       const size_t off = ((size_t)row * a.W + w) * C + chunk * 8;
-      const u32x4 yq = *reinterpret_cast<const u32x4*>(a.y + off);
+      const Raw8<DT> yq = ldraw<DT>(a.y, off);
       const int ow0 = (w + a.pl) / stride, kw0 = (w + a.pl) - ow0 * stride;
       const bool vw[2] = {ow0 < a.OW, kw0 + stride < k && ow0 >= 1};
       const int owc[2] = {ow0 < a.OW ? ow0 : a.OW - 1, ow0 >= 1 ? ow0 - 1 : 0};
       const int kwc[2] = {kw0, kw0 + stride};
       u32x2 pk[4];
-      u32x4 dq[4];
+      Raw8<DT> dq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const size_t o = ((size_t)(n * a.OH + ohc[q >> 1]) * a.OW + owc[q & 1]) * C + chunk * 8;
         pk[q] = *reinterpret_cast<const u32x2*>(a.idx + o);
-        dq[q] = *reinterpret_cast<const u32x4*>(a.dzp + o);
+        dq[q] = ldraw<DT>(a.dzp, o);
       }
       float g[8];
 #pragma unroll
@@ -718,7 +719,7 @@ __global__ __launch_bounds__(TPB) void bn_pool_bwd_kernel(const BnPoolArgs a) {
         const unsigned tap = (vh[q >> 1] && vw[q & 1]) ? (unsigned)(khc[q >> 1] * k + kwc[q & 1])
                                                        : 0x100u;
         float d[8];
-        unpack8(dq[q], d);
+        unpack8<DT>(dq[q], d);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const unsigned t = ((c < 4 ? pk[q].x : pk[q].y) >> (8 * (c & 3))) & 0xffu;
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(TPB) void bn_pool_bwd_kernel(const BnPoolArgs a) {
         }
       }
       float yv[8];
-      unpack8(yq, yv);
+      unpack8<DT>(yq, yv);
       if constexpr (APPLY) {
         float o[8];
 #pragma unroll
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(TPB) void bn_pool_bwd_kernel(const BnPoolArgs a) {
           const float xhat = (yv[c] - mean[c]) * invstd[c];
           o[c] = sc[c] * (g[c] - c1[c] - xhat * c2[c]);
         }
-        *reinterpret_cast<u32x4*>(a.dy + off) = pack8(o);
+        straw<DT>(a.dy, off, o);
       } else {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -809,11 +810,11 @@ void launch_bn_fold(const float* params, const float* state, float* out, const v
 
 size_t bn_workspace_floats() { return (size_t)MAX_PARTIAL_BLOCKS * 2 * 2048; }
 
-void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, uint8_t* mask,
+void launch_bn_fwd_train(const void* y, const void* res, void* z, uint8_t* mask,
                          const float* gamma, const float* beta, float* mm, float* mv,
                          float* save_mean, float* save_invstd, float* scale, float* shift,
                          float* ws, int fused_replicas, int P, int C, float eps, float momentum,
-                         int relu, const float* rscale, const float* rshift, int apply,
+                         int relu, const float* rscale, const float* rshift, int apply, int dt,
                          hipStream_t s) {
   check_channels(C, P);
   if ((rscale == nullptr) != (rshift == nullptr) || (rscale && !res))
@@ -821,7 +822,7 @@ void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, uint8_t*
   int G = fused_replicas;             // > 0: `ws` already holds that many rows of [2][C] sums
   if (G <= 0) {
     G = reduce_grid(P, C);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(G), dim3(TPB), 0, s, y, ws, P, C);
+    DTF_DT_SWITCH(dt, hipLaunchKernelGGL(bn_stats_kernel<DT>, dim3(G), dim3(TPB), 0, s, y, ws, P, C));
   }
   static const bool fold_ok = [] {
     const char* e = std::getenv("DTF_BN_FOLD_FINALIZE");
@@ -831,14 +832,17 @@ void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, uint8_t*
                 ws, G, momentum, mm, mv, save_mean, save_invstd, scale, shift, rscale, rshift};
   if (apply && fold_ok && fused_replicas > 0 && fused_replicas * 2 * C <= 16384 &&
       C <= FOLD_MAX_C) {
-    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
+    DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_apply_kernel<DT, true>), dim3(rows_grid(P, C)),
+                                         dim3(TPB), 0, s, a));
     return;
   }
   BnFinalizeArgs f{ws, G, gamma, beta, mm, mv, save_mean, save_invstd, scale, shift,
                    P, C, eps, momentum};
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, f);
-  if (apply)      // apply == 0: statistics only, a later layer normalises this tensor on the fly
-    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
+  if (apply) {    // apply == 0: statistics only, a later layer normalises this tensor on the fly
+    DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_apply_kernel<DT, false>), dim3(rows_grid(P, C)),
+                                         dim3(TPB), 0, s, a));
+  }
 }
 
 namespace {
@@ -853,17 +857,18 @@ void check_bn_pool(int N, int H, int W, int C, int OH, int OW, int k, int stride
 }
 }  // namespace
 
-void launch_bn_pool_fwd_train(const bf16_t* y, bf16_t* zp, uint8_t* idx, const float* gamma,
+void launch_bn_pool_fwd_train(const void* y, void* zp, uint8_t* idx, const float* gamma,
                               const float* beta, float* mm, float* mv, float* save_mean,
                               float* save_invstd, float* scale, float* shift, float* ws,
                               int fused_replicas, int N, int H, int W, int C, int OH, int OW, int k,
-                              int stride, int pt, int pl, float eps, float momentum, hipStream_t s) {
+                              int stride, int pt, int pl, float eps, float momentum, int dt,
+                              hipStream_t s) {
   check_bn_pool(N, H, W, C, OH, OW, k, stride, pt, pl);
   const int P = N * H * W;
   int G = fused_replicas;
   if (G <= 0) {
     G = reduce_grid(P, C);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(G), dim3(TPB), 0, s, y, ws, P, C);
+    DTF_DT_SWITCH(dt, hipLaunchKernelGGL(bn_stats_kernel<DT>, dim3(G), dim3(TPB), 0, s, y, ws, P, C));
   }
   BnFinalizeArgs f{ws, G, gamma, beta, mm, mv, save_mean, save_invstd, scale, shift,
                    P, C, eps, momentum};
@@ -873,13 +878,14 @@ void launch_bn_pool_fwd_train(const bf16_t* y, bf16_t* zp, uint8_t* idx, const f
   a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.k = k; a.stride = stride;
   a.pt = pt; a.pl = pl;
   const int rows = N * OH;
-  hipLaunchKernelGGL(bn_pool_fwd_kernel, dim3(rows < 8192 ? rows : 8192), dim3(TPB), 0, s, a);
+  DTF_DT_SWITCH(dt, hipLaunchKernelGGL(bn_pool_fwd_kernel<DT>, dim3(rows < 8192 ? rows : 8192),
+                                       dim3(TPB), 0, s, a));
 }
 
-void launch_bn_pool_bwd(const bf16_t* dzp, const uint8_t* idx, const bf16_t* y, const float* mean,
+void launch_bn_pool_bwd(const void* dzp, const uint8_t* idx, const void* y, const float* mean,
                         const float* invstd, const float* gamma, float* dgamma, float* dbeta,
-                        bf16_t* dy, float* ws, int N, int H, int W, int C, int OH, int OW, int k,
-                        int stride, int pt, int pl, hipStream_t s) {
+                        void* dy, float* ws, int N, int H, int W, int C, int OH, int OW, int k,
+                        int stride, int pt, int pl, int dt, hipStream_t s) {
   check_bn_pool(N, H, W, C, OH, OW, k, stride, pt, pl);
   BnPoolArgs a{};
   a.y = y; a.idx = const_cast<uint8_t*>(idx); a.dzp = dzp; a.dy = dy; a.mean = mean; a.invstd = invstd; a.gamma = gamma;
@@ -892,42 +898,48 @@ void launch_bn_pool_bwd(const bf16_t* dzp, const uint8_t* idx, const bf16_t* y, 
   const int cap = (int)(bn_workspace_floats() / (2 * (size_t)C));
   int G = rows < cap ? rows : cap;
   if (G > 4096) G = 4096;
-  if (stride == 2)
-    hipLaunchKernelGGL((bn_pool_bwd_kernel<false, 2>), dim3(G), dim3(TPB), 0, s, a);
-  else
-    hipLaunchKernelGGL((bn_pool_bwd_kernel<false, 0>), dim3(G), dim3(TPB), 0, s, a);
+  if (stride == 2) {
+    DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_pool_bwd_kernel<DT, false, 2>), dim3(G), dim3(TPB), 0, s, a));
+  } else {
+    DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_pool_bwd_kernel<DT, false, 0>), dim3(G), dim3(TPB), 0, s, a));
+  }
   BnBwdArgs b{nullptr, y, nullptr, nullptr, mean, invstd, gamma, dgamma, dbeta, dy, nullptr, ws, G,
               N * H * W, C, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, b);
-  if (stride == 2)
-    hipLaunchKernelGGL((bn_pool_bwd_kernel<true, 2>), dim3(rows < 8192 ? rows : 8192), dim3(TPB), 0, s, a);
-  else
-    hipLaunchKernelGGL((bn_pool_bwd_kernel<true, 0>), dim3(rows < 8192 ? rows : 8192), dim3(TPB), 0, s, a);
+  const int ga = rows < 8192 ? rows : 8192;
+  if (stride == 2) {
+    DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_pool_bwd_kernel<DT, true, 2>), dim3(ga), dim3(TPB), 0, s, a));
+  } else {
+    DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_pool_bwd_kernel<DT, true, 0>), dim3(ga), dim3(TPB), 0, s, a));
+  }
 }
 
-void launch_mask_apply(const bf16_t* x, const uint8_t* mask, bf16_t* out, size_t n, hipStream_t s) {
+void launch_mask_apply(const void* x, const uint8_t* mask, void* out, size_t n, int dt,
+                       hipStream_t s) {
   if (n % 8) throw std::invalid_argument("mask_apply: element count must be a multiple of 8");
   const size_t nvec = n / 8;
   if (nvec == 0) return;
   const size_t blocks = (nvec + TPB - 1) / TPB;
-  hipLaunchKernelGGL(mask_apply_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(TPB), 0,
-                     s, x, mask, out, nvec);
+  DTF_DT_SWITCH(dt, hipLaunchKernelGGL(mask_apply_kernel<DT>,
+                                       dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(TPB),
+                                       0, s, x, mask, out, nvec));
 }
 
-void launch_bn_infer(const bf16_t* y, const bf16_t* res, bf16_t* z, const float* gamma,
+void launch_bn_infer(const void* y, const void* res, void* z, const float* gamma,
                      const float* beta, const float* mm, const float* mv, int P, int C, float eps,
-                     int relu, hipStream_t s) {
+                     int relu, int dt, hipStream_t s) {
   check_channels(C, P);
   BnApplyArgs a{y, res, z, nullptr, nullptr, nullptr, gamma, beta, mm, mv, P, C, eps, relu,
                 nullptr, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                 nullptr, nullptr};
-  hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
+  DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_apply_kernel<DT, false>), dim3(rows_grid(P, C)),
+                                       dim3(TPB), 0, s, a));
 }
 
-void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const uint8_t* mask,
+void launch_bn_bwd(const void* dz, const void* y, const void* z, const uint8_t* mask,
                    const float* mean, const float* invstd, const float* gamma, float* dgamma,
-                   float* dbeta, bf16_t* dy, bf16_t* dres, float* ws, int P, int C,
-                   int pre_replicas, hipStream_t s) {
+                   float* dbeta, void* dy, void* dres, float* ws, int P, int C,
+                   int pre_replicas, int dt, hipStream_t s) {
   check_channels(C, P);
   if (pre_replicas < 0) throw std::invalid_argument("bn_bwd: negative replica count");
   const int G = pre_replicas > 0 ? pre_replicas : reduce_grid(P, C);
@@ -939,33 +951,37 @@ void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const uin
     return !(e && e[0] == '0');
   }();
   if (fold_ok && pre_replicas > 0 && pre_replicas * 2 * C <= 16384 && C <= FOLD_MAX_C) {
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
+    DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, true>), dim3(rows_grid(P, C)),
+                                         dim3(TPB), 0, s, a));
     return;
   }
-  if (pre_replicas == 0)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(G), dim3(TPB), 0, s, a);
+  if (pre_replicas == 0) {
+    DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_reduce_kernel<DT, 1>), dim3(G), dim3(TPB), 0, s, a));
+  }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, a);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
+  DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, false>), dim3(rows_grid(P, C)),
+                                       dim3(TPB), 0, s, a));
 }
 
 // Backward of two BatchNorm layers that receive the same gradient g = dz gated by `mask`
 // (a block's last BatchNorm and the one of its projection shortcut): dz and the mask are
 // read once per sweep for both.  `ws` / `ws2`: a partial-sum workspace per layer.
-void launch_bn_bwd_dual(const bf16_t* dz, const uint8_t* mask, int P, int C, float* ws, float* ws2,
-                        const bf16_t* y1, const float* mean1, const float* invstd1,
-                        const float* gamma1, float* dgamma1, float* dbeta1, bf16_t* dy1,
-                        const bf16_t* y2, const float* mean2, const float* invstd2,
-                        const float* gamma2, float* dgamma2, float* dbeta2, bf16_t* dy2,
-                        hipStream_t s) {
+void launch_bn_bwd_dual(const void* dz, const uint8_t* mask, int P, int C, float* ws, float* ws2,
+                        const void* y1, const float* mean1, const float* invstd1,
+                        const float* gamma1, float* dgamma1, float* dbeta1, void* dy1,
+                        const void* y2, const float* mean2, const float* invstd2,
+                        const float* gamma2, float* dgamma2, float* dbeta2, void* dy2,
+                        int dt, hipStream_t s) {
   check_channels(C, P);
   if (ws == ws2) throw std::invalid_argument("bn_bwd_dual: the two layers need separate workspaces");
   const int G = reduce_grid(P, C);
   BnBwdArgs a{dz, y1, nullptr, mask, mean1, invstd1, gamma1, dgamma1, dbeta1, dy1, nullptr, ws, G,
               P, C, 0, y2, mean2, invstd2, gamma2, dgamma2, dbeta2, dy2, ws2};
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, dim3(G), dim3(TPB), 0, s, a);
+  DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_reduce_kernel<DT, 2>), dim3(G), dim3(TPB), 0, s, a));
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, a);
   BnBwdArgs b = a;                   // the finalize kernel reads the first layer's fields
   b.ws = ws2; b.dgamma = dgamma2; b.dbeta = dbeta2; b.mean = mean2; b.invstd = invstd2;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, b);
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<false, 2>), dim3(rows_grid(P, C)), dim3(TPB), 0, s, a);
+  DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, false, 2>), dim3(rows_grid(P, C)),
+                                       dim3(TPB), 0, s, a));
 }

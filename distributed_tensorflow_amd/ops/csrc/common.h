@@ -10,6 +10,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdexcept>
+#include <string>
+
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -46,6 +49,105 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
   v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
   return v;
 }
+
+// ---- element types of activations / packed weights ---------------------------------------------
+// Kernels that move activations are templates over DT: bfloat16 (the default of the engine),
+// IEEE half (the reference's fp16 mixed precision, `resnet_imagenet_main.py:97-100`) and fp32
+// (the reference's default precision).  Arithmetic is fp32 in all three; only storage differs.
+// Tensor arguments cross the launcher interface as `void*` + DT.
+constexpr int DT_BF16 = 0, DT_F16 = 1, DT_F32 = 2;
+
+template <int DT> struct Elem { typedef uint16_t T; };
+template <> struct Elem<DT_F32> { typedef float T; };
+
+__device__ __forceinline__ float h2f(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+
+template <int DT>
+__device__ __forceinline__ float to_f(typename Elem<DT>::T v) {
+  if constexpr (DT == DT_BF16) return bf2f(v);
+  else if constexpr (DT == DT_F16) return h2f(v);
+  else return v;
+}
+template <int DT>
+__device__ __forceinline__ typename Elem<DT>::T from_f(float f) {
+  if constexpr (DT == DT_BF16) return f2bf(f);
+  else if constexpr (DT == DT_F16) return f2h(f);
+  else return f;
+}
+
+// Eight consecutive elements as they sit in memory: 16 bytes for the 16-bit types, 32 for fp32.
+template <int DT> struct Raw8 { u32x4 v; };
+template <> struct Raw8<DT_F32> { f32x4 lo, hi; };
+
+template <int DT>
+__device__ __forceinline__ Raw8<DT> ldraw(const void* base, size_t off) {
+  Raw8<DT> r;
+  if constexpr (DT == DT_F32) {
+    const float* p = reinterpret_cast<const float*>(base) + off;
+    r.lo = *reinterpret_cast<const f32x4*>(p);
+    r.hi = *reinterpret_cast<const f32x4*>(p + 4);
+  } else {
+    r.v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(base) + off);
+  }
+  return r;
+}
+template <int DT>
+__device__ __forceinline__ Raw8<DT> zero_raw() {
+  Raw8<DT> r;
+  if constexpr (DT == DT_F32) { r.lo = f32x4{0.f, 0.f, 0.f, 0.f}; r.hi = r.lo; }
+  else r.v = u32x4{0u, 0u, 0u, 0u};
+  return r;
+}
+template <int DT>
+__device__ __forceinline__ void unpack8(const Raw8<DT>& r, float* f) {
+  if constexpr (DT == DT_F32) {
+    f[0] = r.lo[0]; f[1] = r.lo[1]; f[2] = r.lo[2]; f[3] = r.lo[3];
+    f[4] = r.hi[0]; f[5] = r.hi[1]; f[6] = r.hi[2]; f[7] = r.hi[3];
+  } else if constexpr (DT == DT_F16) {
+    const uint32_t w[4] = {r.v.x, r.v.y, r.v.z, r.v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[2 * j] = h2f((uint16_t)(w[j] & 0xffffu));
+      f[2 * j + 1] = h2f((uint16_t)(w[j] >> 16));
+    }
+  } else {
+    unpack8(r.v, f);
+  }
+}
+// Stores eight fp32 values as eight consecutive elements at base + off.
+template <int DT>
+__device__ __forceinline__ void straw(void* base, size_t off, const float* f) {
+  if constexpr (DT == DT_F32) {
+    float* p = reinterpret_cast<float*>(base) + off;
+    *reinterpret_cast<f32x4*>(p) = f32x4{f[0], f[1], f[2], f[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{f[4], f[5], f[6], f[7]};
+  } else if constexpr (DT == DT_F16) {
+    u32x4 v;
+    v.x = (uint32_t)f2h(f[0]) | ((uint32_t)f2h(f[1]) << 16);
+    v.y = (uint32_t)f2h(f[2]) | ((uint32_t)f2h(f[3]) << 16);
+    v.z = (uint32_t)f2h(f[4]) | ((uint32_t)f2h(f[5]) << 16);
+    v.w = (uint32_t)f2h(f[6]) | ((uint32_t)f2h(f[7]) << 16);
+    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(base) + off) = v;
+  } else {
+    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(base) + off) = pack8(f);
+  }
+}
+// Two fp32 values packed into one 32-bit word of 16-bit elements (16-bit types only).
+template <int DT>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  if constexpr (DT == DT_F16) return (uint32_t)f2h(lo) | ((uint32_t)f2h(hi) << 16);
+  else return pack2bf(lo, hi);
+}
+
+// Runs `...` with the compile-time constant DT bound to the run-time element type `dt`.
+#define DTF_DT_SWITCH(dt, ...)                                                          \
+  switch (dt) {                                                                         \
+    case DT_BF16: { constexpr int DT = DT_BF16; __VA_ARGS__; } break;                   \
+    case DT_F16: { constexpr int DT = DT_F16; __VA_ARGS__; } break;                     \
+    case DT_F32: { constexpr int DT = DT_F32; __VA_ARGS__; } break;                     \
+    default: throw std::invalid_argument("unknown element type (0: bf16, 1: fp16, 2: fp32)"); \
+  }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -90,8 +90,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
       opix = (size_t)((int)n * p.OHfull + oh * p.OSH + p.OOH) * p.OWfull + (ow * p.OSW + p.OOW);
     }
     const size_t obase = opix * p.ldc;
-    bf16_t* optr = p.out + obase + co0;
-    const bf16_t* aptr = p.addend ? p.addend + obase + co0 : nullptr;
+    bf16_t* optr = reinterpret_cast<bf16_t*>(p.out) + obase + co0;
+    const bf16_t* aptr = p.addend ? reinterpret_cast<const bf16_t*>(p.addend) + obase + co0 : nullptr;
     const uint8_t* mptr = p.addend_mask ? p.addend_mask + opix * (p.ldc >> 3) + (co0 >> 3) : nullptr;
     if constexpr (CPL >= 8) {
 #pragma unroll
@@ -126,7 +126,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
           if (EPI != EPI_INFER && p.stats) {
             const uint32_t w[4] = {o.x, o.y, o.z, o.w};
             if constexpr (BSTATS) {                  // sum g, sum g * y  (g = masked output)
-              const u32x4 yq = *reinterpret_cast<const u32x4*>(p.stats_y + obase + co0 + h * 8);
+              const u32x4 yq = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.stats_y) + obase + co0 + h * 8);
               const uint32_t yw[4] = {yq.x, yq.y, yq.z, yq.w};
               const uint32_t sb = p.stats_mask
                   ? p.stats_mask[opix * (p.ldc >> 3) + (co0 >> 3) + h] : 0xffu;
@@ -187,7 +187,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
         if (EPI != EPI_INFER && p.stats) {
           const uint32_t w[2] = {o.x, o.y};
           if constexpr (BSTATS) {
-            const u32x2 yq = *reinterpret_cast<const u32x2*>(p.stats_y + obase + co0);
+            const u32x2 yq = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.stats_y) + obase + co0);
             const uint32_t yw[2] = {yq.x, yq.y};
             const uint32_t sb = p.stats_mask
                 ? (uint32_t)p.stats_mask[opix * (p.ldc >> 3) + (co0 >> 3)] >> (co0 & 4) : 0xffu;
@@ -239,6 +239,78 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
         const int idx = base + j;
         const int q = idx / CPL, c = idx % CPL;    // quantity (sum / sum of squares), channel
         if (co0 + c < p.Cout) atomicAdd(dst + q * p.Cout + co0 + c, st[j]);
+      }
+    }
+  }
+}
+
+// Epilogue for the element types without fused extras (fp16, fp32; bf16 takes conv_epilogue):
+// out = acc (+ bias) (+ addend, optionally gated by the 1-bit mask), four channels per store.
+template <int DT, int MR, int NR, bool POINTWISE>
+__device__ __forceinline__ void conv_epilogue_plain(const ConvParams& p, f32x4 (&acc)[NR][MR],
+                                                    const int m_base, const int co0,
+                                                    const int lane) {
+  typedef typename Elem<DT>::T T;
+  const int fr = lane & 15;
+  T* out = reinterpret_cast<T*>(p.out);
+  const T* addend = reinterpret_cast<const T*>(p.addend);
+  const bool vec_ok = (p.ldc % 4 == 0);
+#pragma unroll
+  for (int mr = 0; mr < MR; ++mr) {
+    const int m = m_base + mr * 16 + fr;
+    if (m >= p.M) continue;
+    size_t opix;
+    if (POINTWISE) {
+      opix = (size_t)m;
+    } else {
+      const uint32_t t = fd_div((uint32_t)m, p.divOW);
+      const int ow = m - (int)t * p.OW;
+      const uint32_t n = fd_div(t, p.divOH);
+      const int oh = (int)t - (int)n * p.OH;
+      opix = (size_t)((int)n * p.OHfull + oh * p.OSH + p.OOH) * p.OWfull + (ow * p.OSW + p.OOW);
+    }
+    const size_t obase = opix * p.ldc;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+      const int c0 = co0 + nr * 4;                 // this tile's four channels
+      if (c0 >= p.Cout) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        v[e] = acc[nr][mr][e] + ((p.bias && c0 + e < p.Cout) ? p.bias[c0 + e] : 0.f);
+      const uint32_t mbits = p.addend_mask
+          ? ((uint32_t)p.addend_mask[opix * (p.ldc >> 3) + (c0 >> 3)] >> (c0 & 4)) : 0xfu;
+      if (vec_ok && c0 + 4 <= p.Cout) {
+        if (addend) {
+          float a[4];
+          if constexpr (DT == DT_F32) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(addend + obase + c0);
+            a[0] = q[0]; a[1] = q[1]; a[2] = q[2]; a[3] = q[3];
+          } else {
+            const u32x2 q = *reinterpret_cast<const u32x2*>(addend + obase + c0);
+            a[0] = to_f<DT>((uint16_t)(q.x & 0xffffu)); a[1] = to_f<DT>((uint16_t)(q.x >> 16));
+            a[2] = to_f<DT>((uint16_t)(q.y & 0xffffu)); a[3] = to_f<DT>((uint16_t)(q.y >> 16));
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (mbits >> e) & 1u ? a[e] : 0.f;
+        }
+        if constexpr (DT == DT_F32) {
+          *reinterpret_cast<f32x4*>(out + obase + c0) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+          u32x2 o;
+          o.x = pack2<DT>(v[0], v[1]);
+          o.y = pack2<DT>(v[2], v[3]);
+          *reinterpret_cast<u32x2*>(out + obase + c0) = o;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (c0 + e < p.Cout) {
+            float x = v[e];
+            if (addend && ((mbits >> e) & 1u)) x += to_f<DT>(addend[obase + c0 + e]);
+            out[obase + c0 + e] = from_f<DT>(x);
+          }
+        }
       }
     }
   }

@@ -41,11 +41,33 @@
 
 namespace {
 
-constexpr int BK = 32;
+// K-step: one 64-byte LDS row, i.e. 32 elements of a 16-bit type or 16 of fp32
+constexpr int bk_of(int dt) { return dt == DT_F32 ? 16 : 32; }
 
 // 16 bytes of zeros in global memory: the source of every masked direct-to-LDS load.
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};
 
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+// One K-step of a 16x16 output tile from the 16 bytes each lane read of the A (weights) and B
+// (pixels) rows.
+template <int DT>
+__device__ __forceinline__ f32x4 mfma_step(const u32x4& a, const u32x4& b, f32x4 c) {
+  if constexpr (DT == DT_BF16) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  } else if constexpr (DT == DT_F16) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  } else {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    return c;
+  }
+}
 
 // Addressing modes of the gather (template parameter MODE):
 //   GENERIC    every K-step decodes its k index into (tap i, tap j, channel) per lane - needed
@@ -69,9 +91,20 @@ using conv_epi::EPI_PLAIN;
 using conv_epi::EPI_BSTATS;
 using conv_epi::EPI_INFER;
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int EPI = EPI_PLAIN>
+// DT: element type of activations and packed weights (common.h).  An LDS tile row is 64 bytes in
+// every case - a K-step of 32 elements for the 16-bit types, 16 for fp32 - so the DMA, the swizzle
+// and the fragment reads (one ds_read_b128 per row and lane group) are the same instructions;
+// what differs is the matrix instruction: v_mfma_f32_16x16x32_{bf16,f16} takes the 8 elements a
+// lane read as its 8 consecutive K values, fp32 runs four v_mfma_f32_16x16x4_f32 and feeds element
+// e of the lane's chunk to step e (K index 4 * (lane / 16) + e for both operands, so the sum
+// over a row's 16 elements is complete).  fp32 in, fp32 accumulate: exact fp32 products at
+// 1/16 of the 16-bit rate.
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int EPI = EPI_PLAIN>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 4)
 void conv_igemm_kernel(const ConvParams p) {
+  typedef typename Elem<DT>::T T;
+  constexpr int EPC = 16 / (int)sizeof(T);          // elements per 16-byte chunk: 8 or 4
+  constexpr int BK = 64 / (int)sizeof(T);           // elements per K-step (one 64-byte row)
   constexpr bool POINTWISE = MODE == POINTWISE_MODE;
   constexpr int NW = WAVES_M * WAVES_N;             // waves per block: 4, or 8 for the 256x128 tile
   constexpr int RPP = 16 * NW;                      // tile rows filled per pass (16 per wave)
@@ -133,17 +166,17 @@ void conv_igemm_kernel(const ConvParams p) {
       }
     }
   }
-  const bf16_t* __restrict__ gin = p.in;
-  const bf16_t* __restrict__ gw = p.wgt;
-  const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_zero_page);
+  const T* __restrict__ gin = reinterpret_cast<const T*>(p.in);
+  const T* __restrict__ gw = reinterpret_cast<const T*>(p.wgt);
+  const T* zero_page = reinterpret_cast<const T*>(g_zero_page);
 
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
 
   // ---- TAPLOOP state: one pointer (+ per-step increment: 64 bytes, or 0 on the zero page)
   // per load, recomputed when the wave-uniform tap (tli, tlj) changes --------------------
-  const bf16_t* xptr[XV];
-  const bf16_t* wptr[WV];
+  const T* xptr[XV];
+  const T* wptr[WV];
   int xinc[XV], winc[WV];
   int tli = 0, tlj = 0, tlc = 0;                   // current tap and K-steps done inside it
   const int steps_per_tap = p.Ctap / BK;
@@ -153,10 +186,10 @@ void conv_igemm_kernel(const ConvParams p) {
       const int hi = xh[r] + tli * p.dhs;
       const int wi = xw[r] + tlj * p.dws;
       const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      xptr[r] = ok ? gin + ((size_t)(xbase[r] + hi * p.W + wi) * p.Cpix + kvx * 8) : zero_page;
+      xptr[r] = ok ? gin + ((size_t)(xbase[r] + hi * p.W + wi) * p.Cpix + kvx * EPC) : zero_page;
       xinc[r] = ok ? BK : 0;
     }
-    const int wk = p.wk0 + tli * p.wsi + tlj * p.wsj + kvw * 8;
+    const int wk = p.wk0 + tli * p.wsi + tlj * p.wsj + kvw * EPC;
 #pragma unroll
     for (int r = 0; r < WV; ++r) {
       const int co = n0 + lrow + RPP * r;
@@ -188,8 +221,8 @@ void conv_igemm_kernel(const ConvParams p) {
   };
 
   // running decomposition of the two k indices into (tap i, tap j, channel c)
-  int kkx = kvx * 8, kcx = kvx * 8, tix = 0, tjx = 0;
-  int kkw = kvw * 8, kcw = kvw * 8, tiw = 0, tjw = 0;
+  int kkx = kvx * EPC, kcx = kvx * EPC, tix = 0, tjx = 0;
+  int kkw = kvw * EPC, kcw = kvw * EPC, tiw = 0, tjw = 0;
   if (!POINTWISE) {
     while (kcx >= p.Ctap) { kcx -= p.Ctap; if (++tjx == p.TJ) { tjx = 0; ++tix; } }
     while (kcw >= p.Ctap) { kcw -= p.Ctap; if (++tjw == p.TJ) { tjw = 0; ++tiw; } }
@@ -201,7 +234,7 @@ void conv_igemm_kernel(const ConvParams p) {
     const bool kvalx = kkx < p.Ktotal;
 #pragma unroll
     for (int r = 0; r < XV; ++r) {
-      const bf16_t* src;
+      const T* src;
       if (POINTWISE) {
         const bool ok = kvalx && xbase[r] >= 0;
         src = ok ? gin + ((size_t)xbase[r] * p.Cpix + kkx) : zero_page;
@@ -220,7 +253,7 @@ void conv_igemm_kernel(const ConvParams p) {
       if (RPP * r + wave * 16 < BN) {               // wave-uniform: whole 16-row pieces only
         const int co = n0 + lrow + RPP * r;
         const bool ok = kvalw && co < p.Cout;
-        const bf16_t* src = ok ? gw + ((size_t)co * p.ldw + wk) : zero_page;
+        const T* src = ok ? gw + ((size_t)co * p.ldw + wk) : zero_page;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ws + r * (RPP * 64) + wave * 1024), 16, 0, 0);
       }
     }
@@ -281,24 +314,29 @@ void conv_igemm_kernel(const ConvParams p) {
     }
     const uint8_t* xs = smem + buf * (XBYTES + WBYTES);
     const uint8_t* ws = xs + XBYTES;
-    bf16x8 wf[NR], xf[MR];
+    u32x4 wf[NR], xf[MR];
 #pragma unroll
-    for (int nr = 0; nr < NR; ++nr) wf[nr] = *reinterpret_cast<const bf16x8*>(ws + woff[nr]);
+    for (int nr = 0; nr < NR; ++nr) wf[nr] = *reinterpret_cast<const u32x4*>(ws + woff[nr]);
 #pragma unroll
-    for (int mr = 0; mr < MR; ++mr) xf[mr] = *reinterpret_cast<const bf16x8*>(xs + xoff[mr]);
+    for (int mr = 0; mr < MR; ++mr) xf[mr] = *reinterpret_cast<const u32x4*>(xs + xoff[mr]);
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
       for (int mr = 0; mr < MR; ++mr)
-        acc[nr][mr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nr], xf[mr], acc[nr][mr], 0, 0, 0);
+        acc[nr][mr] = mfma_step<DT>(wf[nr], xf[mr], acc[nr][mr]);
     dma_wait_all();
     __syncthreads();
   }
 
-  conv_epi::conv_epilogue<MR, NR, POINTWISE, EPI>(p, acc, m0 + wm * WM, n0 + wn * WN + fq * 4 * NR, mt, lane);
+  if constexpr (DT == DT_BF16)
+    conv_epi::conv_epilogue<MR, NR, POINTWISE, EPI>(p, acc, m0 + wm * WM,
+                                                    n0 + wn * WN + fq * 4 * NR, mt, lane);
+  else
+    conv_epi::conv_epilogue_plain<DT, MR, NR, POINTWISE>(p, acc, m0 + wm * WM,
+                                                         n0 + wn * WN + fq * 4 * NR, lane);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
 void launch_cfg_epi(const ConvParams& p, hipStream_t stream) {
   const int tilesN = (p.Cout + BN - 1) / BN;
   const int tilesM = (p.M + BM - 1) / BM;
@@ -308,21 +346,26 @@ void launch_cfg_epi(const ConvParams& p, hipStream_t stream) {
                          p.OH == p.H && p.OW == p.W && p.OHfull == p.OH && p.OWfull == p.OW &&
                          p.Ctap <= p.Cpix;
   if (pointwise)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, POINTWISE_MODE, EPI>),
+    hipLaunchKernelGGL((conv_igemm_kernel<DT, BM, BN, WAVES_M, WAVES_N, POINTWISE_MODE, EPI>),
                        dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
-  else if (p.Ctap % BK == 0)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, TAPLOOP, EPI>), dim3(grid),
+  else if (p.Ctap % bk_of(DT) == 0)
+    hipLaunchKernelGGL((conv_igemm_kernel<DT, BM, BN, WAVES_M, WAVES_N, TAPLOOP, EPI>), dim3(grid),
                        dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, GENERIC, EPI>), dim3(grid),
+    hipLaunchKernelGGL((conv_igemm_kernel<DT, BM, BN, WAVES_M, WAVES_N, GENERIC, EPI>), dim3(grid),
                        dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
 }
 
+// The fused epilogues (BatchNorm statistics, folded inference BatchNorm) exist for bfloat16, the
+// type the engine is tuned for; fp16 / fp32 launches take the plain epilogue (bias, addend) and
+// the planner schedules the separate statistics sweep / BatchNorm launch for them.
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 void launch_cfg(const ConvParams& p, hipStream_t stream) {
-  if (p.scale) launch_cfg_epi<BM, BN, WAVES_M, WAVES_N, EPI_INFER>(p, stream);
-  else if (p.stats_y) launch_cfg_epi<BM, BN, WAVES_M, WAVES_N, EPI_BSTATS>(p, stream);
-  else launch_cfg_epi<BM, BN, WAVES_M, WAVES_N, EPI_PLAIN>(p, stream);
+  if (p.dt == DT_F16) return launch_cfg_epi<DT_F16, BM, BN, WAVES_M, WAVES_N, EPI_PLAIN>(p, stream);
+  if (p.dt == DT_F32) return launch_cfg_epi<DT_F32, BM, BN, WAVES_M, WAVES_N, EPI_PLAIN>(p, stream);
+  if (p.scale) launch_cfg_epi<DT_BF16, BM, BN, WAVES_M, WAVES_N, EPI_INFER>(p, stream);
+  else if (p.stats_y) launch_cfg_epi<DT_BF16, BM, BN, WAVES_M, WAVES_N, EPI_BSTATS>(p, stream);
+  else launch_cfg_epi<DT_BF16, BM, BN, WAVES_M, WAVES_N, EPI_PLAIN>(p, stream);
 }
 
 }  // namespace
@@ -332,6 +375,9 @@ void launch_cfg(const ConvParams& p, hipStream_t stream) {
 void validate_conv_params(const ConvParams& p) {
   auto fail = [](const std::string& m) { throw std::invalid_argument("conv_igemm: " + m); };
   if (!p.in || !p.wgt || !p.out) fail("null tensor pointer");
+  if (p.dt != DT_BF16 && p.dt != DT_F16 && p.dt != DT_F32) fail("unknown element type");
+  if (p.dt != DT_BF16 && (p.scale || p.stats || p.relu))
+    fail("fused statistics / folded BatchNorm epilogues exist for bfloat16 only");
   if (p.N <= 0 || p.H <= 0 || p.W <= 0 || p.OH <= 0 || p.OW <= 0) fail("bad spatial size");
   if (p.M != p.N * p.OH * p.OW) fail("M != N*OH*OW");
   if ((int64_t)p.N * p.H * p.W >= (1ll << 31) / 8) fail("input too large for 32-bit pixel index");
@@ -381,7 +427,7 @@ void validate_conv_params(const ConvParams& p) {
 void launch_conv_igemm(const ConvParams& p, int cfg, hipStream_t stream) {
   validate_conv_params(p);
   if (cfg >= 16) {
-    if (launch_conv_pipe(p, cfg, stream)) return;
+    if (p.dt == DT_BF16 && launch_conv_pipe(p, cfg, stream)) return;
     cfg = pipe_fallback_cfg(cfg);
   }
   switch (cfg) {

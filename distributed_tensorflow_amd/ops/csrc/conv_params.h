@@ -5,10 +5,11 @@
 
 // Forward / data-gradient gather GEMM; see conv_igemm.hip for the formula.
 struct ConvParams {
-  const bf16_t* in = nullptr;      // [N, H, W, Cpix]
-  const bf16_t* wgt = nullptr;     // packed [Cout][ldw], K contiguous
-  bf16_t* out = nullptr;           // [N, OHfull, OWfull, ldc]
-  const bf16_t* addend = nullptr;  // optional tensor added to the result (same layout as out)
+  int dt = DT_BF16;                // element type of in / wgt / out / addend (common.h)
+  const void* in = nullptr;        // [N, H, W, Cpix]
+  const void* wgt = nullptr;       // packed [Cout][ldw], K contiguous
+  void* out = nullptr;             // [N, OHfull, OWfull, ldc]
+  const void* addend = nullptr;    // optional tensor added to the result (same layout as out)
   // optional 1-bit mask of the addend, [pixels][ldc/8] bytes in the layout of `out`: only
   // elements whose bit is set are added (the ReLU mask of a residual branch's gradient)
   const uint8_t* addend_mask = nullptr;
@@ -44,8 +45,9 @@ struct ConvParams {
 // Weight gradient: dW[k][co] += sum over pixels of X[pixel, k] * dY[pixel, co], where
 // k = (tap i, tap j, channel c) gathers X exactly like the forward pass.
 struct WgradParams {
-  const bf16_t* x = nullptr;       // forward input [N, H, W, Cpix]
-  const bf16_t* dy = nullptr;      // output gradient [N, OH, OW, ldy]
+  int dt = DT_BF16;                // element type of x / dy
+  const void* x = nullptr;         // forward input [N, H, W, Cpix]
+  const void* dy = nullptr;        // output gradient [N, OH, OW, ldy]
   float* dw = nullptr;             // fp32 [TIr*TJr*Creal][Cout] (Keras HWIO), accumulated atomically
   int N = 0, H = 0, W = 0, Cpix = 0;
   int OH = 0, OW = 0, P = 0;       // P = N*OH*OW pixels (the reduction dimension)

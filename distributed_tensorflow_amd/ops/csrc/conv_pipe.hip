@@ -147,8 +147,8 @@ void conv_pipe_kernel(const ConvParams p) {
     kvw[r] = pc ^ swz_w<BK, NR>(row);
     wco[r] = n0 + row;
   }
-  const bf16_t* __restrict__ gin = p.in;
-  const bf16_t* __restrict__ gw = p.wgt;
+  const bf16_t* __restrict__ gin = reinterpret_cast<const bf16_t*>(p.in);
+  const bf16_t* __restrict__ gw = reinterpret_cast<const bf16_t*>(p.wgt);
   const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_zero_page_p);
 
   typedef const __attribute__((address_space(1))) void* gptr_t;

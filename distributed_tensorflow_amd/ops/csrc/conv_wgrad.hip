@@ -36,11 +36,18 @@ constexpr int BP = 32;  // pixels per reduction step
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page_w[4] = {0u, 0u, 0u, 0u};
 
 typedef __attribute__((address_space(3))) short4v lds_short4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8w;
 
-// Byte offset of 16-byte chunk `ch` of pixel row `row` inside a [32][WIDTH] bf16 tile.
-template <int WIDTH>
+// Byte offset of 16-byte chunk `ch` of pixel row `row` inside a [32][WIDTH] tile of ES-byte
+// elements.  16-bit types: swizzled for the transposing reads.  fp32: fragments are read with
+// ds_read_b32, 16 consecutive channels of pixel rows r and r + 1 per 32-lane half; rows are a
+// multiple of 128 bytes apart, so odd rows swap their 64-byte halves to land on the other banks.
+template <int WIDTH, int ES = 2>
 __device__ __forceinline__ int tile_off(int row, int ch) {
-  if constexpr (WIDTH == 128 || WIDTH == 256) {
+  if constexpr (ES == 4) {
+    if constexpr (WIDTH >= 32) return row * (WIDTH * 4) + ((ch ^ ((row & 1) << 2)) << 4);
+    else return row * (WIDTH * 4) + ch * 16;
+  } else if constexpr (WIDTH == 128 || WIDTH == 256) {
     // rows are a whole number of 256-byte bank rows: XOR the low three bits of the 32-byte
     // chunk index with a function that differs for the 8 rows one half-wave touches
     const int f = (row & 3) | (((row >> 3) & 1) << 2);
@@ -75,8 +82,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // waves per SIMD the register allocation must allow: what the LDS ring admits, at most 4
-constexpr int wgrad_occ(int bkk, int bco, int threads, int g, int stages) {
-  const int lds = g * stages * BP * (bkk + bco) * 2;
+constexpr int wgrad_occ(int bkk, int bco, int threads, int g, int stages, int es) {
+  const int lds = g * stages * BP * (bkk + bco) * es;
   int bpc = (160 * 1024) / lds;
   if (bpc < 1) bpc = 1;
   const int w = bpc * threads / 256;
@@ -87,17 +94,26 @@ constexpr int wgrad_occ(int bkk, int bco, int threads, int g, int stages) {
 // step.  STAGES = 3, 4: the tiles of STAGES - 1 steps stay in flight; a wave waits with a counted
 // `s_waitcnt vmcnt(n)` for the step it is about to multiply and the block meets at a raw
 // `s_barrier`, which does not drain the vector-memory counter (same scheme as conv_pipe.hip).
-template <int BKK, int BCO, int WAVES_K, int WAVES_C, int G, bool POINTWISE, int STAGES>
+//
+// DT: element type of X and dY.  bf16 / fp16 use the transposing reads and
+// v_mfma_f32_16x16x32_{bf16,f16}; fp32 reads single elements (a lane owns channel lane % 16 of
+// pixel 4 * step + lane / 16) and runs v_mfma_f32_16x16x4_f32, eight per 32-pixel step.
+template <int DT, int BKK, int BCO, int WAVES_K, int WAVES_C, int G, bool POINTWISE, int STAGES>
 __global__ __launch_bounds__(64 * WAVES_K * WAVES_C * G,
-                             wgrad_occ(BKK, BCO, 64 * WAVES_K * WAVES_C * G, G, STAGES))
+                             wgrad_occ(BKK, BCO, 64 * WAVES_K * WAVES_C * G, G, STAGES,
+                                       DT == DT_F32 ? 4 : 2))
 void conv_wgrad_kernel(const WgradParams p) {
+  typedef typename Elem<DT>::T T;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int EPC = 16 / ES;                                  // elements per 16-byte chunk
   constexpr int GT = 64 * WAVES_K * WAVES_C;                    // threads per wave group
   constexpr int WKK = BKK / WAVES_K, WCO = BCO / WAVES_C;
   constexpr int KR = WKK / 16, CR = WCO / 16;
-  constexpr int XCPR = BKK / 8, YCPR = BCO / 8;                 // 16-byte chunks per tile row
+  constexpr int XCPR = BKK / EPC, YCPR = BCO / EPC;             // 16-byte chunks per tile row
   constexpr int XRPP = GT / XCPR, YRPP = GT / YCPR;             // tile rows filled per pass
   constexpr int XV = (BP + XRPP - 1) / XRPP, YV = (BP + YRPP - 1) / YRPP;
-  constexpr int XBYTES = BP * BKK * 2, YBYTES = BP * BCO * 2;
+  constexpr int XBYTES = BP * BKK * ES, YBYTES = BP * BCO * ES;
+  static_assert(XCPR <= 64 && YCPR <= 64, "a tile row is at most one DMA instruction");
   static_assert(GT == 256 || GT == 512, "4 or 8 waves per group");
   static_assert(GT * G <= 1024, "block size");
   static_assert(WKK % 16 == 0 && WCO % 16 == 0, "tile shape");
@@ -135,12 +151,13 @@ void conv_wgrad_kernel(const WgradParams p) {
   // ---- X (input) gather geometry: this thread always loads the same 8 k-columns ----------
   const int xrow = tid / XCPR, yrow = tid / YCPR;
   auto unswizzle = [](int width, int row, int slot) {
+    if (ES == 4) return width >= 32 ? (slot ^ ((row & 1) << 2)) : slot;
     if (width == 128 || width == 256) return ((((slot >> 1) ^ ((row & 3) | (((row >> 3) & 1) << 2))) << 1) | (slot & 1));
     if (width == 64) return ((((slot >> 1) ^ (((row >> 1) & 1) | (((row >> 3) & 1) << 1))) << 1) | (slot & 1));
     return slot;
   };
   const int xch = unswizzle(BKK, xrow, tid % XCPR);     // same for every row this lane fills
-  const int kcol = k0 + xch * 8;
+  const int kcol = k0 + xch * EPC;
   const bool xk_ok = kcol < p.Ktotal;
   int kc = 0, ti = 0, tj = 0;
   if (!POINTWISE && xk_ok) {
@@ -152,12 +169,12 @@ void conv_wgrad_kernel(const WgradParams p) {
   const int tap_h = p.dh0 + ti * p.dhs, tap_w = p.dw0 + tj * p.dws;
   // ---- dY geometry -------------------------------------------------------------------------
   const int ych = unswizzle(BCO, yrow, tid % YCPR);
-  const int ycol = c0 + ych * 8;
+  const int ycol = c0 + ych * EPC;
   const bool yc_ok = ycol < p.Cout;
 
-  const bf16_t* __restrict__ gx = p.x;
-  const bf16_t* __restrict__ gy = p.dy;
-  const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_zero_page_w);
+  const T* __restrict__ gx = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ gy = reinterpret_cast<const T*>(p.dy);
+  const T* zero_page = reinterpret_cast<const T*>(g_zero_page_w);
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -170,7 +187,7 @@ void conv_wgrad_kernel(const WgradParams p) {
         const int row = xrow + XRPP * r;
         const int pp = pstep + row;
         bool ok = xk_ok && pp < pend;
-        const bf16_t* src = zero_page;
+        const T* src = zero_page;
         if (POINTWISE) {
           if (ok) src = gx + ((size_t)pp * p.Cpix + kcol);
         } else {
@@ -191,7 +208,7 @@ void conv_wgrad_kernel(const WgradParams p) {
         const int row = yrow + YRPP * r;
         const int pp = pstep + row;
         const bool ok = yc_ok && pp < pend;
-        const bf16_t* src = ok ? gy + ((size_t)pp * p.ldy + ycol) : zero_page;
+        const T* src = ok ? gy + ((size_t)pp * p.ldy + ycol) : zero_page;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ys + r * (GT * 16) + wave * 1024), 16, 0, 0);
       }
     }
@@ -209,16 +226,45 @@ void conv_wgrad_kernel(const WgradParams p) {
   auto multiply = [&](int sbyte) {
     const uint8_t* xs = smem + sbyte;
     const uint8_t* ys = xs + XBYTES;
-    bf16x8 xf[KR], yf[CR];
+    if constexpr (DT == DT_F32) {
+      const int g = lane >> 4, idx = lane & 15;
 #pragma unroll
-    for (int a = 0; a < KR; ++a) xf[a] = read_tr_frag<BKK>(xs, wk * WKK + a * 16, lane);
+      for (int st = 0; st < BP / 4; ++st) {
+        const int row = 4 * st + g;
+        float xa[KR], yb[CR];
 #pragma unroll
-    for (int b = 0; b < CR; ++b) yf[b] = read_tr_frag<BCO>(ys, wc * WCO + b * 16, lane);
+        for (int a = 0; a < KR; ++a) {
+          const int col = wk * WKK + a * 16 + idx;
+          xa[a] = *reinterpret_cast<const float*>(xs + tile_off<BKK, 4>(row, col >> 2) + (col & 3) * 4);
+        }
 #pragma unroll
-    for (int a = 0; a < KR; ++a)
+        for (int b = 0; b < CR; ++b) {
+          const int col = wc * WCO + b * 16 + idx;
+          yb[b] = *reinterpret_cast<const float*>(ys + tile_off<BCO, 4>(row, col >> 2) + (col & 3) * 4);
+        }
 #pragma unroll
-      for (int b = 0; b < CR; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], yf[b], acc[a][b], 0, 0, 0);
+        for (int a = 0; a < KR; ++a)
+#pragma unroll
+          for (int b = 0; b < CR; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[a], yb[b], acc[a][b], 0, 0, 0);
+      }
+    } else {
+      bf16x8 xf[KR], yf[CR];
+#pragma unroll
+      for (int a = 0; a < KR; ++a) xf[a] = read_tr_frag<BKK>(xs, wk * WKK + a * 16, lane);
+#pragma unroll
+      for (int b = 0; b < CR; ++b) yf[b] = read_tr_frag<BCO>(ys, wc * WCO + b * 16, lane);
+#pragma unroll
+      for (int a = 0; a < KR; ++a)
+#pragma unroll
+        for (int b = 0; b < CR; ++b) {
+          if constexpr (DT == DT_F16)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                __builtin_bit_cast(f16x8w, xf[a]), __builtin_bit_cast(f16x8w, yf[b]), acc[a][b], 0, 0, 0);
+          else
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], yf[b], acc[a][b], 0, 0, 0);
+        }
+    }
   };
   if constexpr (STAGES == 2) {
     issue_tile(pbeg + grp * BP, 0);
@@ -320,7 +366,7 @@ void conv_wgrad_kernel(const WgradParams p) {
   }
 }
 
-template <int BKK, int BCO, int WAVES_K, int WAVES_C, int G, int STAGES>
+template <int DT, int BKK, int BCO, int WAVES_K, int WAVES_C, int G, int STAGES>
 void launch_stg(const WgradParams& p, hipStream_t stream) {
   const int tilesK = (p.Ktotal + BKK - 1) / BKK;
   const int tilesC = (p.Cout + BCO - 1) / BCO;
@@ -328,10 +374,10 @@ void launch_stg(const WgradParams& p, hipStream_t stream) {
                          p.dw0 == 0 && p.OH == p.H && p.OW == p.W && p.Ctap <= p.Cpix;
   dim3 grid(tilesK * tilesC, p.splits);
   if (pointwise)
-    hipLaunchKernelGGL((conv_wgrad_kernel<BKK, BCO, WAVES_K, WAVES_C, G, true, STAGES>), grid,
+    hipLaunchKernelGGL((conv_wgrad_kernel<DT, BKK, BCO, WAVES_K, WAVES_C, G, true, STAGES>), grid,
                        dim3(64 * WAVES_K * WAVES_C * G), 0, stream, p);
   else
-    hipLaunchKernelGGL((conv_wgrad_kernel<BKK, BCO, WAVES_K, WAVES_C, G, false, STAGES>), grid,
+    hipLaunchKernelGGL((conv_wgrad_kernel<DT, BKK, BCO, WAVES_K, WAVES_C, G, false, STAGES>), grid,
                        dim3(64 * WAVES_K * WAVES_C * G), 0, stream, p);
 }
 
@@ -341,12 +387,23 @@ void launch_grp(const WgradParams& p, int stages, hipStream_t stream) {
   // tiles at least 64 wide) and whose ring fits the LDS
   constexpr int GT = 64 * WAVES_K * WAVES_C;
   constexpr bool uniform = GT / (BKK / 8) <= BP && GT / (BCO / 8) <= BP;
-  if (stages == 2) return launch_stg<BKK, BCO, WAVES_K, WAVES_C, G, 2>(p, stream);
+  if (p.dt != DT_BF16) {
+    // fp16 / fp32: the two-stage kernel (these paths are bound by the matrix rate - fp32 - or
+    // exist for parity with the reference's precision flags, not for the last few percent)
+    if (stages != 2) throw std::invalid_argument("conv_wgrad: deep pipelines are bfloat16 only");
+    if (p.dt == DT_F16) return launch_stg<DT_F16, BKK, BCO, WAVES_K, WAVES_C, G, 2>(p, stream);
+    if constexpr (G * 2 * BP * (BKK + BCO) * 4 <= 160 * 1024 && BKK / 4 <= 64 && BCO / 4 <= 64) {
+      return launch_stg<DT_F32, BKK, BCO, WAVES_K, WAVES_C, G, 2>(p, stream);
+    } else {
+      throw std::invalid_argument("conv_wgrad: tile / group combination too large for fp32");
+    }
+  }
+  if (stages == 2) return launch_stg<DT_BF16, BKK, BCO, WAVES_K, WAVES_C, G, 2>(p, stream);
   if constexpr (uniform && G * 3 * BP * (BKK + BCO) * 2 <= 160 * 1024) {
-    if (stages == 3) return launch_stg<BKK, BCO, WAVES_K, WAVES_C, G, 3>(p, stream);
+    if (stages == 3) return launch_stg<DT_BF16, BKK, BCO, WAVES_K, WAVES_C, G, 3>(p, stream);
   }
   if constexpr (uniform && G * 4 * BP * (BKK + BCO) * 2 <= 160 * 1024) {
-    if (stages == 4) return launch_stg<BKK, BCO, WAVES_K, WAVES_C, G, 4>(p, stream);
+    if (stages == 4) return launch_stg<DT_BF16, BKK, BCO, WAVES_K, WAVES_C, G, 4>(p, stream);
   }
   throw std::invalid_argument("conv_wgrad: this tile has no pipeline of that depth");
 }
@@ -371,6 +428,7 @@ void launch_cfg(const WgradParams& p, int groups, int stages, hipStream_t stream
 void validate_wgrad_params(const WgradParams& p) {
   auto fail = [](const std::string& m) { throw std::invalid_argument("conv_wgrad: " + m); };
   if (!p.x || !p.dy || !p.dw) fail("null tensor pointer");
+  if (p.dt != DT_BF16 && p.dt != DT_F16 && p.dt != DT_F32) fail("unknown element type");
   if (p.P != p.N * p.OH * p.OW || p.P <= 0) fail("P != N*OH*OW");
   if ((int64_t)p.N * p.H * p.W >= (1ll << 31) / 8) fail("input too large for 32-bit pixel index");
   if (p.Ctap % 8 || p.Ctap <= 0) fail("Ctap must be a positive multiple of 8");

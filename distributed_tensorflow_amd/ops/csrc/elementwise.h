@@ -1,4 +1,5 @@
 // Launchers of the bandwidth-bound kernels (BatchNorm, pooling, loss, optimizer, packing).
+// Activation tensors are `void*` plus the element type `dt` (DT_BF16 / DT_F16 / DT_F32, common.h).
 #pragma once
 #include "common.h"
 
@@ -6,58 +7,62 @@ size_t bn_workspace_floats();
 // `mask` (optional): one bit per element of the ReLU mask, [P][C/8] bytes, written as 32-bit
 // words: the buffer must be 4-byte aligned with room for P*C/8 rounded up to 4 bytes.
 // `fused_replicas` > 0: `ws` holds that many rows of [2][C] sums left by the convolution.
-void launch_bn_fwd_train(const bf16_t* y, const bf16_t* res, bf16_t* z, uint8_t* mask,
+void launch_bn_fwd_train(const void* y, const void* res, void* z, uint8_t* mask,
                          const float* gamma, const float* beta, float* mm, float* mv,
                          float* save_mean, float* save_invstd, float* scale, float* shift,
                          float* ws, int fused_replicas, int P, int C, float eps, float momentum,
-                         int relu, const float* rscale, const float* rshift, int apply,
+                         int relu, const float* rscale, const float* rshift, int apply, int dt,
                          hipStream_t s);
 // Folded inference constants of every BatchNorm layer (descriptor layout: see bn.hip).
 int bn_fold_desc_size();
 void launch_bn_fold(const float* params, const float* state, float* out, const void* descs,
                     int nlayers, hipStream_t s);
 // BatchNorm + ReLU + max-pool in one sweep (forward) and the matching backward, see bn.hip.
-void launch_bn_pool_fwd_train(const bf16_t* y, bf16_t* zp, uint8_t* idx, const float* gamma,
+void launch_bn_pool_fwd_train(const void* y, void* zp, uint8_t* idx, const float* gamma,
                               const float* beta, float* mm, float* mv, float* save_mean,
                               float* save_invstd, float* scale, float* shift, float* ws,
                               int fused_replicas, int N, int H, int W, int C, int OH, int OW, int k,
-                              int stride, int pt, int pl, float eps, float momentum, hipStream_t s);
-void launch_bn_pool_bwd(const bf16_t* dzp, const uint8_t* idx, const bf16_t* y, const float* mean,
+                              int stride, int pt, int pl, float eps, float momentum, int dt,
+                              hipStream_t s);
+void launch_bn_pool_bwd(const void* dzp, const uint8_t* idx, const void* y, const float* mean,
                         const float* invstd, const float* gamma, float* dgamma, float* dbeta,
-                        bf16_t* dy, float* ws, int N, int H, int W, int C, int OH, int OW, int k,
-                        int stride, int pt, int pl, hipStream_t s);
-void launch_bn_bwd_dual(const bf16_t* dz, const uint8_t* mask, int P, int C, float* ws, float* ws2,
-                        const bf16_t* y1, const float* mean1, const float* invstd1,
-                        const float* gamma1, float* dgamma1, float* dbeta1, bf16_t* dy1,
-                        const bf16_t* y2, const float* mean2, const float* invstd2,
-                        const float* gamma2, float* dgamma2, float* dbeta2, bf16_t* dy2,
-                        hipStream_t s);
-void launch_bn_infer(const bf16_t* y, const bf16_t* res, bf16_t* z, const float* gamma,
+                        void* dy, float* ws, int N, int H, int W, int C, int OH, int OW, int k,
+                        int stride, int pt, int pl, int dt, hipStream_t s);
+void launch_bn_bwd_dual(const void* dz, const uint8_t* mask, int P, int C, float* ws, float* ws2,
+                        const void* y1, const float* mean1, const float* invstd1,
+                        const float* gamma1, float* dgamma1, float* dbeta1, void* dy1,
+                        const void* y2, const float* mean2, const float* invstd2,
+                        const float* gamma2, float* dgamma2, float* dbeta2, void* dy2,
+                        int dt, hipStream_t s);
+void launch_bn_infer(const void* y, const void* res, void* z, const float* gamma,
                      const float* beta, const float* mm, const float* mv, int P, int C, float eps,
-                     int relu, hipStream_t s);
-void launch_bn_bwd(const bf16_t* dz, const bf16_t* y, const bf16_t* z, const uint8_t* mask,
+                     int relu, int dt, hipStream_t s);
+void launch_bn_bwd(const void* dz, const void* y, const void* z, const uint8_t* mask,
                    const float* mean, const float* invstd, const float* gamma, float* dgamma,
-                   float* dbeta, bf16_t* dy, bf16_t* dres, float* ws, int P, int C,
-                   int pre_replicas, hipStream_t s);
+                   float* dbeta, void* dy, void* dres, float* ws, int P, int C,
+                   int pre_replicas, int dt, hipStream_t s);
 
 // out[i] = bit (i % 8) of mask[i / 8] ? x[i] : 0, n a multiple of 8 (materialises a masked
 // gradient when its consumer cannot apply the mask itself).
-void launch_mask_apply(const bf16_t* x, const uint8_t* mask, bf16_t* out, size_t n, hipStream_t s);
+void launch_mask_apply(const void* x, const uint8_t* mask, void* out, size_t n, int dt,
+                       hipStream_t s);
 
-void launch_maxpool_fwd(const bf16_t* x, bf16_t* out, uint8_t* idx, int N, int H, int W, int C,
-                        int OH, int OW, int k, int stride, int pt, int pl, hipStream_t s);
-void launch_maxpool_bwd(const bf16_t* dy, const uint8_t* idx, bf16_t* dx, int N, int H, int W,
-                        int C, int OH, int OW, int k, int stride, int pt, int pl, hipStream_t s);
-void launch_global_mean_fwd(const bf16_t* x, bf16_t* out, int N, int HW, int C, hipStream_t s);
-void launch_global_mean_bwd(const bf16_t* dy, bf16_t* dx, int N, int HW, int C, hipStream_t s);
+void launch_maxpool_fwd(const void* x, void* out, uint8_t* idx, int N, int H, int W, int C,
+                        int OH, int OW, int k, int stride, int pt, int pl, int dt, hipStream_t s);
+void launch_maxpool_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int H, int W,
+                        int C, int OH, int OW, int k, int stride, int pt, int pl, int dt,
+                        hipStream_t s);
+void launch_global_mean_fwd(const void* x, void* out, int N, int HW, int C, int dt, hipStream_t s);
+void launch_global_mean_bwd(const void* dy, void* dx, int N, int HW, int C, int dt, hipStream_t s);
 
 // Fused softmax + cross-entropy (+ gradient) over bf16 logits with row pitch ld.
 // accum[0] += sum of per-row losses, accum[1] += number of rows whose argmax equals the label.
-void launch_softmax_xent(const bf16_t* logits, const int32_t* labels, bf16_t* dlogits,
+void launch_softmax_xent(const void* logits, const int32_t* labels, void* dlogits,
                          float* accum, int N, int C, int ld, float grad_scale,
-                         const float* grad_scale_dev, hipStream_t s);
-void launch_softmax_probs(const bf16_t* logits, float* probs, int N, int C, int ld, hipStream_t s);
-void launch_colsum(const bf16_t* x, float* out, int N, int C, int ld, hipStream_t s);
+                         const float* grad_scale_dev, int dt, hipStream_t s);
+void launch_softmax_probs(const void* logits, float* probs, int N, int C, int ld, int dt,
+                          hipStream_t s);
+void launch_colsum(const void* x, float* out, int N, int C, int ld, int dt, hipStream_t s);
 
 void launch_sgd_momentum_l2(float* p, const float* g, float* v, const float* l2x2, size_t n,
                             float lr, float momentum, float grad_scale, int use_momentum,
@@ -73,10 +78,10 @@ struct PackDesc {
   int64_t count;                      // elements of the packed copy
   int64_t first_block;                // first thread block that works on this entry
 };
-void launch_pack_weights(const float* params, bf16_t* packed, const PackDesc* descs, int ndesc,
-                         int nblocks, hipStream_t s);
+void launch_pack_weights(const float* params, void* packed, const PackDesc* descs, int ndesc,
+                         int nblocks, int dt, hipStream_t s);
 
-void launch_preprocess_pad(const float* in, bf16_t* out, int N, int H, int W, int Cin, int pt,
-                           int pl, int OH, int OW, int Cpad, hipStream_t s);
+void launch_preprocess_pad(const float* in, void* out, int N, int H, int W, int Cin, int pt,
+                           int pl, int OH, int OW, int Cpad, int dt, hipStream_t s);
 void launch_zero(void* ptr, size_t nbytes, hipStream_t s);
-void launch_cast_f32_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
+void launch_cast_from_f32(const float* in, void* out, size_t n, int dt, hipStream_t s);

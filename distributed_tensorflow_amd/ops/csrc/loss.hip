@@ -1,8 +1,8 @@
-// Fused softmax + cross-entropy forward/backward over bf16 logits (fp32 math).
+// Fused softmax + cross-entropy forward/backward over bf16 / fp16 / fp32 logits (fp32 math).
 //
 // One 256-thread block per row.  The row is read once into registers (up to 16 values per
 // thread, C <= 4096), then: block max -> block sum of exp -> loss = log(sum) + max - logit[y],
-// gradient (softmax - onehot) * grad_scale written as bf16 (padding columns up to the row
+// gradient (softmax - onehot) * grad_scale written in the logits' type (padding columns up to the row
 // pitch are zero-filled so that the dense-layer gradient GEMMs can read whole vectors),
 // and the first-argmax == label test for the accuracy counter.
 #include <stdexcept>
@@ -35,23 +35,26 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return v;
 }
 
-template <bool PROBS>
+template <int DT, bool PROBS>
 __global__ __launch_bounds__(TPB) void softmax_xent_kernel(
-    const bf16_t* __restrict__ logits, const int32_t* __restrict__ labels,
-    bf16_t* __restrict__ dlogits, float* __restrict__ probs, float* accum, int N, int C, int ld,
+    const void* __restrict__ logits_v, const int32_t* __restrict__ labels,
+    void* __restrict__ dlogits_v, float* __restrict__ probs, float* accum, int N, int C, int ld,
     float grad_scale, const float* __restrict__ grad_scale_dev) {
+  typedef typename Elem<DT>::T T;
+  const T* logits = reinterpret_cast<const T*>(logits_v);
+  T* dlogits = reinterpret_cast<T*>(dlogits_v);
   if (grad_scale_dev) grad_scale = grad_scale * grad_scale_dev[0];
   __shared__ float red[4];
   __shared__ int redi[4];
   const int row = blockIdx.x;
-  const bf16_t* lr = logits + (size_t)row * ld;
+  const T* lr = logits + (size_t)row * ld;
   float v[MAXV];
   float mx = -INFINITY;
   int amax = 0x7fffffff;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = threadIdx.x + i * TPB;
-    v[i] = c < C ? bf2f(lr[c]) : -INFINITY;
+    v[i] = c < C ? to_f<DT>(lr[c]) : -INFINITY;
     if (v[i] > mx) { mx = v[i]; amax = c; }
   }
   const float bmax = block_max(mx, red);
@@ -79,26 +82,28 @@ __global__ __launch_bounds__(TPB) void softmax_xent_kernel(
   }
   const int label = labels[row];
   if (dlogits) {
-    bf16_t* dr = dlogits + (size_t)row * ld;
+    T* dr = dlogits + (size_t)row * ld;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int c = threadIdx.x + i * TPB;
       if (c < ld) {
         float g = 0.f;
         if (c < C) g = (v[i] * inv - (c == label ? 1.f : 0.f)) * grad_scale;
-        dr[c] = f2bf(g);
+        dr[c] = from_f<DT>(g);
       }
     }
   }
   if (threadIdx.x == 0) {
-    const float ly = (label >= 0 && label < C) ? bf2f(lr[label]) : 0.f;
+    const float ly = (label >= 0 && label < C) ? to_f<DT>(lr[label]) : 0.f;
     atomicAdd(accum + 0, logf(sum) + bmax - ly);
     if (arg == label) atomicAdd(accum + 1, 1.f);
   }
 }
 
-__global__ void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int N, int C,
+template <int DT>
+__global__ void colsum_kernel(const void* __restrict__ xv, float* __restrict__ out, int N, int C,
                               int ld) {
+  const typename Elem<DT>::T* x = reinterpret_cast<const typename Elem<DT>::T*>(xv);
   // blockIdx.y owns a slice of the rows: a handful of columns-wide blocks walking all rows one
   // dependent load after the other took 99 us on [256 x 1001]
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -107,28 +112,32 @@ __global__ void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ 
   const int n0 = blockIdx.y * per, n1 = min(N, n0 + per);
   float s = 0.f;
 #pragma unroll 4
-  for (int n = n0; n < n1; ++n) s += bf2f(x[(size_t)n * ld + c]);
+  for (int n = n0; n < n1; ++n) s += to_f<DT>(x[(size_t)n * ld + c]);
   if (n1 > n0) atomicAdd(out + c, s);
 }
 
 }  // namespace
 
-void launch_softmax_xent(const bf16_t* logits, const int32_t* labels, bf16_t* dlogits,
+void launch_softmax_xent(const void* logits, const int32_t* labels, void* dlogits,
                          float* accum, int N, int C, int ld, float grad_scale,
-                         const float* grad_scale_dev, hipStream_t s) {
+                         const float* grad_scale_dev, int dt, hipStream_t s) {
   if (C > TPB * MAXV || ld > TPB * MAXV || ld < C)
     throw std::invalid_argument("softmax_xent: at most 4096 classes, ld >= C");
-  hipLaunchKernelGGL((softmax_xent_kernel<false>), dim3(N), dim3(TPB), 0, s, logits, labels,
-                     dlogits, nullptr, accum, N, C, ld, grad_scale, grad_scale_dev);
+  DTF_DT_SWITCH(dt, hipLaunchKernelGGL((softmax_xent_kernel<DT, false>), dim3(N), dim3(TPB), 0, s,
+                                       logits, labels, dlogits, (float*)nullptr, accum, N, C, ld,
+                                       grad_scale, grad_scale_dev));
 }
 
-void launch_softmax_probs(const bf16_t* logits, float* probs, int N, int C, int ld, hipStream_t s) {
+void launch_softmax_probs(const void* logits, float* probs, int N, int C, int ld, int dt,
+                          hipStream_t s) {
   if (C > TPB * MAXV || ld < C) throw std::invalid_argument("softmax_probs: at most 4096 classes");
-  hipLaunchKernelGGL((softmax_xent_kernel<true>), dim3(N), dim3(TPB), 0, s, logits, nullptr,
-                     nullptr, probs, nullptr, N, C, ld, 1.f, nullptr);
+  DTF_DT_SWITCH(dt, hipLaunchKernelGGL((softmax_xent_kernel<DT, true>), dim3(N), dim3(TPB), 0, s,
+                                       logits, (const int32_t*)nullptr, (void*)nullptr, probs,
+                                       (float*)nullptr, N, C, ld, 1.f, (const float*)nullptr));
 }
 
-void launch_colsum(const bf16_t* x, float* out, int N, int C, int ld, hipStream_t s) {
+void launch_colsum(const void* x, float* out, int N, int C, int ld, int dt, hipStream_t s) {
   const int slices = N >= 64 ? 64 : (N > 0 ? N : 1);
-  hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, slices), dim3(256), 0, s, x, out, N, C, ld);
+  DTF_DT_SWITCH(dt, hipLaunchKernelGGL(colsum_kernel<DT>, dim3((C + 255) / 256, slices), dim3(256),
+                                       0, s, x, out, N, C, ld));
 }

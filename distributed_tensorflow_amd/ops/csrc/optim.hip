@@ -64,8 +64,9 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 
 constexpr int PACK_PER_BLOCK = 256 * 8;   // packed elements handled by one block
 
+template <int DT>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ params,
-                                                           bf16_t* __restrict__ packed,
+                                                           void* __restrict__ packed_v,
                                                            const PackDesc* __restrict__ descs,
                                                            int ndesc) {
   // binary search: last descriptor whose first_block <= blockIdx.x
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
   }
   const PackDesc d = descs[lo];
   const float* src = params + d.src_off;
-  bf16_t* dst = packed + d.dst_off;
+  typename Elem<DT>::T* dst = reinterpret_cast<typename Elem<DT>::T*>(packed_v) + d.dst_off;
   if (d.mode == 0) {
     // dst[co][ti][tjp][cp] from src[ti][tj][ci][co]: a transpose between the two innermost
     // dimensions.  One block moves a tile of 32 cp x 64 co of one tap through LDS so that both
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
       for (int k = 0; k < 8; ++k) {
         const int c = (threadIdx.x >> 5) + 8 * k, co = co0 + c;
         if (cp < d.Cpad && co < d.Cout)
-          dst[(((int64_t)co * d.TI + ti) * d.TJpad + tjp) * d.Cpad + cp] = f2bf(tile[r][c]);
+          dst[(((int64_t)co * d.TI + ti) * d.TJpad + tjp) * d.Cpad + cp] = from_f<DT>(tile[r][c]);
       }
     }
     return;
@@ -123,12 +124,13 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     const int ci = (int)(r / d.TI);
     float val = 0.f;
     if (cop < d.Cout) val = src[((int64_t)(ti * d.TJ + tj) * d.Cin + ci) * d.Cout + cop];
-    dst[i] = f2bf(val);
+    dst[i] = from_f<DT>(val);
   }
 }
 
+template <int DT>
 __global__ __launch_bounds__(256) void preprocess_pad_kernel(const float* __restrict__ in,
-                                                             bf16_t* __restrict__ out, int N,
+                                                             void* __restrict__ out_v, int N,
                                                              int H, int W, int Cin, int pt, int pl,
                                                              int OH, int OW, int Cpad) {
   const size_t total = (size_t)N * OH * OW;
@@ -141,8 +143,8 @@ __global__ __launch_bounds__(256) void preprocess_pad_kernel(const float* __rest
     const int h = oh - pt, w = ow - pl;
     const bool inside = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
     const float* src = in + ((size_t)(n * H + (inside ? h : 0)) * W + (inside ? w : 0)) * Cin;
-    bf16_t* dst = out + i * Cpad;
-    for (int c = 0; c < Cpad; ++c) dst[c] = f2bf((inside && c < Cin) ? src[c] : 0.f);
+    typename Elem<DT>::T* dst = reinterpret_cast<typename Elem<DT>::T*>(out_v) + i * Cpad;
+    for (int c = 0; c < Cpad; ++c) dst[c] = from_f<DT>((inside && c < Cin) ? src[c] : 0.f);
   }
 }
 
@@ -158,11 +160,13 @@ __global__ __launch_bounds__(256) void zero_kernel(u32x4* __restrict__ p, size_t
   if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
 }
 
+template <int DT>
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ in,
-                                                   bf16_t* __restrict__ out, size_t n) {
+                                                   void* __restrict__ out_v, size_t n) {
+  typename Elem<DT>::T* out = reinterpret_cast<typename Elem<DT>::T*>(out_v);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x)
-    out[i] = f2bf(in[i]);
+    out[i] = from_f<DT>(in[i]);
 }
 
 inline int grid_for(size_t total) {
@@ -182,18 +186,19 @@ void launch_sgd_momentum_l2(float* p, const float* g, float* v, const float* l2x
                      lr, momentum, grad_scale, use_momentum, hyper);
 }
 
-void launch_pack_weights(const float* params, bf16_t* packed, const PackDesc* descs, int ndesc,
-                         int nblocks, hipStream_t s) {
+void launch_pack_weights(const float* params, void* packed, const PackDesc* descs, int ndesc,
+                         int nblocks, int dt, hipStream_t s) {
   if (ndesc <= 0 || nblocks <= 0) return;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(nblocks), dim3(256), 0, s, params, packed, descs,
-                     ndesc);
+  DTF_DT_SWITCH(dt, hipLaunchKernelGGL(pack_weights_kernel<DT>, dim3(nblocks), dim3(256), 0, s,
+                                       params, packed, descs, ndesc));
 }
 
-void launch_preprocess_pad(const float* in, bf16_t* out, int N, int H, int W, int Cin, int pt,
-                           int pl, int OH, int OW, int Cpad, hipStream_t s) {
+void launch_preprocess_pad(const float* in, void* out, int N, int H, int W, int Cin, int pt,
+                           int pl, int OH, int OW, int Cpad, int dt, hipStream_t s) {
   if (Cpad < Cin) throw std::invalid_argument("preprocess_pad: Cpad < Cin");
-  hipLaunchKernelGGL(preprocess_pad_kernel, dim3(grid_for((size_t)N * OH * OW)), dim3(256), 0, s,
-                     in, out, N, H, W, Cin, pt, pl, OH, OW, Cpad);
+  DTF_DT_SWITCH(dt, hipLaunchKernelGGL(preprocess_pad_kernel<DT>,
+                                       dim3(grid_for((size_t)N * OH * OW)), dim3(256), 0, s, in,
+                                       out, N, H, W, Cin, pt, pl, OH, OW, Cpad));
 }
 
 void launch_zero(void* ptr, size_t nbytes, hipStream_t s) {
@@ -205,6 +210,6 @@ void launch_zero(void* ptr, size_t nbytes, hipStream_t s) {
                      reinterpret_cast<uint8_t*>(ptr) + n16 * 16, ntail);
 }
 
-void launch_cast_f32_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
-  hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
+void launch_cast_from_f32(const float* in, void* out, size_t n, int dt, hipStream_t s) {
+  DTF_DT_SWITCH(dt, hipLaunchKernelGGL(cast_kernel<DT>, dim3(grid_for(n)), dim3(256), 0, s, in, out, n));
 }

@@ -1,4 +1,4 @@
-// Max-pool (TensorFlow SAME padding) and global mean pool for NHWC bf16 activations.
+// Max-pool (TensorFlow SAME padding) and global mean pool for NHWC activations (bf16 / fp16 / fp32 storage).
 //
 // Forward max-pool stores the winning tap (0 .. k*k-1, first maximum in row-major tap order)
 // as one byte per output element; backward is then a gather: every input pixel checks the at
@@ -13,8 +13,9 @@ namespace {
 
 // Both max-pool kernels walk the tensor one image row per block iteration: the (n, row) split is
 // one 32-bit division per row instead of three 64-bit divisions per 16-byte access.
+template <int DT>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(
-    const bf16_t* __restrict__ x, bf16_t* __restrict__ out, uint8_t* __restrict__ idx, int N,
+    const void* __restrict__ x, void* __restrict__ out, uint8_t* __restrict__ idx, int N,
     int H, int W, int C, int OH, int OW, int k, int stride, int pt, int pl) {
   const uint32_t cpr = (uint32_t)C >> 3;
   const uint32_t per_row = (uint32_t)OW * cpr;
@@ -33,8 +34,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(
           const int wi = (int)ow * stride - pl + kw;
           if ((unsigned)wi >= (unsigned)W) continue;
           float f[8];
-          unpack8(*reinterpret_cast<const u32x4*>(
-                      x + ((size_t)(n * H + hi) * W + wi) * C + chunk * 8), f);
+          unpack8<DT>(ldraw<DT>(x, ((size_t)(n * H + hi) * W + wi) * C + chunk * 8), f);
           const int tap = kh * k + kw;
 #pragma unroll
           for (int c = 0; c < 8; ++c)
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(
         }
       }
       const size_t o = ((size_t)row * OW + ow) * C + chunk * 8;
-      *reinterpret_cast<u32x4*>(out + o) = pack8(best);
+      straw<DT>(out, o, best);
       u32x2 pk;
       pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
       pk.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(
   }
 }
 
+template <int DT>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(
-    const bf16_t* __restrict__ dy, const uint8_t* __restrict__ idx, bf16_t* __restrict__ dx, int N,
+    const void* __restrict__ dy, const uint8_t* __restrict__ idx, void* __restrict__ dx, int N,
     int H, int W, int C, int OH, int OW, int k, int stride, int pt, int pl) {
   const uint32_t cpr = (uint32_t)C >> 3;
   const uint32_t per_row = (uint32_t)W * cpr;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(
           const size_t o = ((size_t)(n * OH + oh) * OW + ow) * C + chunk * 8;
           const u32x2 pk = *reinterpret_cast<const u32x2*>(idx + o);
           float d[8];
-          unpack8(*reinterpret_cast<const u32x4*>(dy + o), d);
+          unpack8<DT>(ldraw<DT>(dy, o), d);
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
             const unsigned t = ((c < 4 ? pk.x : pk.y) >> (8 * (c & 3))) & 0xffu;
@@ -88,13 +89,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(
           }
         }
       }
-      *reinterpret_cast<u32x4*>(dx + ((size_t)row * W + w) * C + chunk * 8) = pack8(g);
+      straw<DT>(dx, ((size_t)row * W + w) * C + chunk * 8, g);
     }
   }
 }
 
-__global__ __launch_bounds__(256) void global_mean_fwd_kernel(const bf16_t* __restrict__ x,
-                                                              bf16_t* __restrict__ out, int N,
+template <int DT>
+__global__ __launch_bounds__(256) void global_mean_fwd_kernel(const void* __restrict__ x,
+                                                              void* __restrict__ out, int N,
                                                               int HW, int C) {
   const int cpr = C >> 3;
   const int total = N * cpr;
@@ -106,18 +108,19 @@ __global__ __launch_bounds__(256) void global_mean_fwd_kernel(const bf16_t* __re
   for (int c = 0; c < 8; ++c) s[c] = 0.f;
   for (int p = 0; p < HW; ++p) {
     float f[8];
-    unpack8(*reinterpret_cast<const u32x4*>(x + ((size_t)n * HW + p) * C + chunk * 8), f);
+    unpack8<DT>(ldraw<DT>(x, ((size_t)n * HW + p) * C + chunk * 8), f);
 #pragma unroll
     for (int c = 0; c < 8; ++c) s[c] += f[c];
   }
   const float inv = 1.f / (float)HW;
 #pragma unroll
   for (int c = 0; c < 8; ++c) s[c] *= inv;
-  *reinterpret_cast<u32x4*>(out + (size_t)n * C + chunk * 8) = pack8(s);
+  straw<DT>(out, (size_t)n * C + chunk * 8, s);
 }
 
-__global__ __launch_bounds__(256) void global_mean_bwd_kernel(const bf16_t* __restrict__ dy,
-                                                              bf16_t* __restrict__ dx, int N,
+template <int DT>
+__global__ __launch_bounds__(256) void global_mean_bwd_kernel(const void* __restrict__ dy,
+                                                              void* __restrict__ dx, int N,
                                                               int HW, int C) {
   const int cpr = C >> 3;
   const size_t total = (size_t)N * HW * cpr;
@@ -128,10 +131,10 @@ __global__ __launch_bounds__(256) void global_mean_bwd_kernel(const bf16_t* __re
     const size_t pix = i / cpr;
     const int n = (int)(pix / HW);
     float f[8];
-    unpack8(*reinterpret_cast<const u32x4*>(dy + (size_t)n * C + chunk * 8), f);
+    unpack8<DT>(ldraw<DT>(dy, (size_t)n * C + chunk * 8), f);
 #pragma unroll
     for (int c = 0; c < 8; ++c) f[c] *= inv;
-    *reinterpret_cast<u32x4*>(dx + pix * C + chunk * 8) = pack8(f);
+    straw<DT>(dx, pix * C + chunk * 8, f);
   }
 }
 
@@ -142,32 +145,38 @@ inline int grid_for(size_t total) {
 
 }  // namespace
 
-void launch_maxpool_fwd(const bf16_t* x, bf16_t* out, uint8_t* idx, int N, int H, int W, int C,
-                        int OH, int OW, int k, int stride, int pt, int pl, hipStream_t s) {
+void launch_maxpool_fwd(const void* x, void* out, uint8_t* idx, int N, int H, int W, int C,
+                        int OH, int OW, int k, int stride, int pt, int pl, int dt, hipStream_t s) {
   if (C % 8 || k * k > 255) throw std::invalid_argument("maxpool: C %% 8 != 0 or window too large");
   if ((int64_t)N * H * W * (C / 8) >= (1ll << 31)) throw std::invalid_argument("maxpool: tensor too large");
   const int rows = N * OH;
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(rows < 8192 ? rows : 8192), dim3(256),
-                     0, s, x, out, idx, N, H, W, C, OH, OW, k, stride, pt, pl);
+  DTF_DT_SWITCH(dt, hipLaunchKernelGGL(maxpool_fwd_kernel<DT>, dim3(rows < 8192 ? rows : 8192),
+                                       dim3(256), 0, s, x, out, idx, N, H, W, C, OH, OW, k, stride,
+                                       pt, pl));
 }
 
-void launch_maxpool_bwd(const bf16_t* dy, const uint8_t* idx, bf16_t* dx, int N, int H, int W,
-                        int C, int OH, int OW, int k, int stride, int pt, int pl, hipStream_t s) {
+void launch_maxpool_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int H, int W,
+                        int C, int OH, int OW, int k, int stride, int pt, int pl, int dt,
+                        hipStream_t s) {
   if (C % 8) throw std::invalid_argument("maxpool: C %% 8 != 0");
   if ((int64_t)N * H * W * (C / 8) >= (1ll << 31)) throw std::invalid_argument("maxpool: tensor too large");
   const int rows = N * H;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(rows < 8192 ? rows : 8192), dim3(256), 0,
-                     s, dy, idx, dx, N, H, W, C, OH, OW, k, stride, pt, pl);
+  DTF_DT_SWITCH(dt, hipLaunchKernelGGL(maxpool_bwd_kernel<DT>, dim3(rows < 8192 ? rows : 8192),
+                                       dim3(256), 0, s, dy, idx, dx, N, H, W, C, OH, OW, k, stride,
+                                       pt, pl));
 }
 
-void launch_global_mean_fwd(const bf16_t* x, bf16_t* out, int N, int HW, int C, hipStream_t s) {
+void launch_global_mean_fwd(const void* x, void* out, int N, int HW, int C, int dt,
+                            hipStream_t s) {
   if (C % 8) throw std::invalid_argument("global_mean: C %% 8 != 0");
-  hipLaunchKernelGGL(global_mean_fwd_kernel, dim3((N * (C / 8) + 255) / 256), dim3(256), 0, s, x,
-                     out, N, HW, C);
+  DTF_DT_SWITCH(dt, hipLaunchKernelGGL(global_mean_fwd_kernel<DT>, dim3((N * (C / 8) + 255) / 256),
+                                       dim3(256), 0, s, x, out, N, HW, C));
 }
 
-void launch_global_mean_bwd(const bf16_t* dy, bf16_t* dx, int N, int HW, int C, hipStream_t s) {
+void launch_global_mean_bwd(const void* dy, void* dx, int N, int HW, int C, int dt,
+                            hipStream_t s) {
   if (C % 8) throw std::invalid_argument("global_mean: C %% 8 != 0");
-  hipLaunchKernelGGL(global_mean_bwd_kernel, dim3(grid_for((size_t)N * HW * (C / 8))), dim3(256),
-                     0, s, dy, dx, N, HW, C);
+  DTF_DT_SWITCH(dt, hipLaunchKernelGGL(global_mean_bwd_kernel<DT>,
+                                       dim3(grid_for((size_t)N * HW * (C / 8))), dim3(256), 0, s,
+                                       dy, dx, N, HW, C));
 }

@@ -47,20 +47,18 @@ SUPPORTED_LOSSES = ("sparse_categorical_crossentropy", "categorical_crossentropy
 
 def _pick_executor_kind(requested: str, device: torch.device, dtype: str,
                         spec: Optional[ModelSpec] = None) -> str:
-  """auto: the native engine for 16-bit training on a GPU, PyTorch ops otherwise.
+  """auto: the native engine on a GPU, PyTorch ops on the CPU.
 
-  The native engine's 16-bit format is bfloat16 (fp32 accumulation, fp32 master weights).
-  `--dtype fp16`, the reference's mixed-precision switch (`resnet_imagenet_main.py:97-100`),
-  selects the same engine: activations are then bfloat16 rather than IEEE half, and the loss
-  scale the fp16 recipe asks for is still applied and removed (it is harmless with bfloat16's
-  fp32-sized exponent).  `--executor torch` runs true fp16 through PyTorch instead."""
+  The native engine stores activations as bfloat16 (the type it is tuned for), IEEE half
+  (`--dtype fp16`, the reference's mixed-precision switch `resnet_imagenet_main.py:97-100`, with
+  its loss scale) or fp32 (the reference's default precision): fp32 accumulation and fp32 master
+  weights in all three.  `--executor torch` runs any of them through PyTorch's operators."""
   if requested != "auto":
     return requested
-  if device.type == "cuda" and dtype in ("bf16", "bfloat16", "fp16"):
+  if device.type == "cuda" and dtype in ("bf16", "bfloat16", "fp16", "fp32"):
     if spec is not None:
       from ..engine import hip_executor  # pylint: disable=import-outside-toplevel
       if not hip_executor.supports(spec):
-        # e.g. the trivial model (Flatten -> Dense(1) -> Dense): no convolution to plan around
         logging.warning("model %s has ops without a native kernel: running it with PyTorch ops",
                         spec.name)
         return "torch"
@@ -144,13 +142,11 @@ class Model:
     if ex is None:
       if self.executor_kind == "hip":
         from ..engine.hip_executor import HipExecutor  # pylint: disable=import-outside-toplevel
-        if self.dtype == "fp16":
-          logging.warning("--dtype fp16: the native engine computes in bfloat16")
         if self.data_format == "channels_first":
           logging.warning("data_format channels_first has no effect on the native engine: its "
                           "kernels are written for pixel-major (NHWC) activations; results do "
                           "not depend on the layout")
-        ex = HipExecutor(self.spec, self.store, batch, "bf16", self._bucket_list(),
+        ex = HipExecutor(self.spec, self.store, batch, self.dtype, self._bucket_list(),
                          use_graph=self.use_hip_graph,
                          fused_bn_stats=False if self.deterministic else None)
       else:

@@ -1,0 +1,349 @@
+"""The native kernels instantiated for fp16 and fp32 storage (GPU).
+
+bfloat16 is the engine's own type and is covered by test_hip_kernels.py / test_hip_executor.py.
+fp32 is the reference's default precision (`resnet_imagenet_main.py:97-100`: only `--dtype fp16`
+switches the policy) and fp16 its mixed-precision mode; both run on the same hand-written
+kernels, with `v_mfma_f32_16x16x4_f32` resp. `v_mfma_f32_16x16x32_f16` as the matrix instruction.
+fp32 results are compared with PyTorch fp32 at 1e-4: products and sums are exact fp32, only the
+summation order differs.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from distributed_tensorflow_amd import models
+from distributed_tensorflow_amd.models.graph import same_padding
+from distributed_tensorflow_amd.ops.conv_plan import ConvGeom, round_up
+
+TORCH = {1: torch.float16, 2: torch.float32}
+TOL = {1: 2e-2, 2: 1e-4}
+
+
+def _native():
+  from distributed_tensorflow_amd.ops import native
+  native.ext()
+  return native
+
+
+def _pack(native, g, w_hwio, which, dt):
+  dev = w_hwio.device
+  d = g.pack_fwd() if which == "fwd" else g.pack_dgrad()
+  d.update(src_off=0, dst_off=0, first_block=0)
+  out = torch.zeros(round_up(d["count"], 8), dtype=TORCH[dt], device=dev)
+  desc = torch.frombuffer(bytearray(native.pack_desc_bytes([d])), dtype=torch.uint8).to(dev)
+  native.run_op("pack_weights", dict(params=w_hwio.contiguous().data_ptr(), packed=out.data_ptr(),
+                                     descs=desc.data_ptr(), ndesc=1,
+                                     nblocks=native.pack_blocks(d), dt=dt))
+  torch.cuda.synchronize()
+  return out
+
+
+def _ref_conv(x_nhwc, w_hwio, stride, pad):
+  pt, pb, pl, pr = pad
+  x = F.pad(x_nhwc.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+  return F.conv2d(x, w_hwio.permute(3, 2, 0, 1), None, stride).permute(0, 2, 3, 1)
+
+
+@pytest.fixture(autouse=True)
+def _exact_fp32_reference():
+  """The PyTorch reference must itself be plain fp32 (no reduced-precision convolution mode)."""
+  old = (torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32)
+  torch.backends.cudnn.allow_tf32 = False
+  torch.backends.cuda.matmul.allow_tf32 = False
+  yield
+  torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = old
+
+
+CASES = [
+    # N, H, W, Cin, K, Cout, stride
+    (2, 14, 14, 64, 1, 256, 1),       # pointwise
+    (3, 15, 13, 64, 3, 64, 1),        # 3x3, ragged M, tap loop
+    (2, 16, 16, 128, 3, 128, 2),      # stride 2 (TF SAME 0/1), four parity data gradients
+    (2, 16, 16, 256, 1, 512, 2),      # strided projection
+    (2, 9, 9, 16, 3, 16, 1),          # CIFAR channels
+    (2, 8, 8, 24, 3, 40, 1),          # channels per tap not a multiple of the K-step: generic gather
+    (4, 7, 7, 512, 3, 512, 1),        # K = 4608
+    (5, 1, 1, 2048, 1, 1001, 1),      # the dense head as a 1x1 convolution, ragged Cout
+]
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_dgrad_wgrad_other_types(case, dt):
+  native = _native()
+  N, H, W, Cin, K, Cout, stride = case
+  dev = torch.device("cuda")
+  gen = torch.Generator(device="cpu").manual_seed(sum(case) * 3 + dt)
+  pad = same_padding(H, K, stride) + same_padding(W, K, stride)
+  g = ConvGeom(N, H, W, Cin, K, K, Cout, stride, pad, dt=dt)
+  td = TORCH[dt]
+  x = torch.randn(N, H, W, Cin, generator=gen).to(td).to(dev)
+  w = (torch.randn(K, K, Cin, Cout, generator=gen) * (1.0 / math.sqrt(K * K * Cin))).to(dev)
+  wq = w.to(td).float()
+  tol = TOL[dt]
+  # forward
+  wf = _pack(native, g, w, "fwd", dt)
+  out = torch.full(g.output_shape, float("nan"), dtype=td, device=dev)
+  native.run_op("conv", g.fwd(x.data_ptr(), wf.data_ptr(), out.data_ptr()))
+  torch.cuda.synchronize()
+  ref = _ref_conv(x.float(), wq, stride, pad)
+  err = (out.float()[..., :Cout] - ref).abs().max().item()
+  assert err <= tol * ref.abs().max().item() + tol * 1e-1, err
+  # data gradient, plain and accumulating
+  dy = torch.randn(N, g.OH, g.OW, g.ldc, generator=gen).to(td).to(dev)
+  dy[..., Cout:] = 0
+  xr = x.float().requires_grad_(True)
+  wr = wq.clone().requires_grad_(True)
+  _ref_conv(xr, wr, stride, pad).backward(dy.float()[..., :Cout])
+  wd = _pack(native, g, w, "dgrad", dt)
+  dx = torch.full((N, H, W, Cin), float("nan"), dtype=td, device=dev)
+  for d in g.dgrad(dy.data_ptr(), wd.data_ptr(), dx.data_ptr()):
+    native.run_op("conv", d)
+  torch.cuda.synchronize()
+  err = (dx.float() - xr.grad).abs().max().item()
+  assert err <= tol * xr.grad.abs().max().item() + tol * 1e-1, err
+  dx2 = dx.clone()
+  for d in g.dgrad(dy.data_ptr(), wd.data_ptr(), dx2.data_ptr(), accumulate=True):
+    native.run_op("conv", d)
+  torch.cuda.synchronize()
+  assert torch.allclose(dx2.float(), 2 * dx.float(), rtol=4 * tol, atol=4 * tol)
+  # weight gradient, default tile and a forced split
+  for extra in ({}, {"cfg": 1, "splits": 3}, {"cfg": 16, "splits": 2}):
+    dw = torch.zeros(K, K, Cin, Cout, dtype=torch.float32, device=dev)
+    native.run_op("wgrad", dict(g.wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr()), **extra))
+    torch.cuda.synchronize()
+    err = (dw - wr.grad).abs().max().item()
+    assert err <= tol * wr.grad.abs().max().item() + tol * 1e-1, (extra, err)
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+def test_dgrad_masked_addend_other_types(dt):
+  """dX = dgrad(dY) + addend gated by a bit mask (the deferred residual gradient)."""
+  native = _native()
+  dev = torch.device("cuda")
+  td = TORCH[dt]
+  N, H, W, Cin, K, Cout = 2, 9, 9, 72, 3, 64
+  gen = torch.Generator(device="cpu").manual_seed(5 + dt)
+  pad = same_padding(H, K, 1) + same_padding(W, K, 1)
+  g = ConvGeom(N, H, W, Cin, K, K, Cout, 1, pad, dt=dt)
+  w = (torch.randn(K, K, Cin, Cout, generator=gen) * 0.05).to(dev)
+  dy = torch.randn(N, H, W, Cout, generator=gen).to(td).to(dev)
+  add = torch.randn(N, H, W, Cin, generator=gen).to(td).to(dev)
+  bits = torch.randint(0, 2, (N, H, W, Cin), generator=gen).to(dev)
+  mask = (bits.reshape(-1, 8) << torch.arange(8, device=dev)).sum(1).to(torch.uint8)
+  xr = torch.zeros(N, H, W, Cin, device=dev, requires_grad=True)
+  _ref_conv(xr, w.to(td).float(), 1, pad).backward(dy.float())
+  want = xr.grad + add.float() * bits
+  wd = _pack(native, g, w, "dgrad", dt)
+  dx = torch.full((N, H, W, Cin), float("nan"), dtype=td, device=dev)
+  for d in g.dgrad(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), addend=add.data_ptr(),
+                   addend_mask=mask.data_ptr()):
+    native.run_op("conv", d)
+  torch.cuda.synchronize()
+  assert (dx.float() - want).abs().max().item() <= TOL[dt] * want.abs().max().item() + 1e-3
+  out = torch.empty_like(add)
+  native.run_op("mask_apply", dict(x=add.data_ptr(), mask=mask.data_ptr(), out=out.data_ptr(),
+                                   n=add.numel(), dt=dt))
+  torch.cuda.synchronize()
+  assert torch.equal(out.float(), add.float() * bits)
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("C,relu,residual", [(64, True, True), (256, True, False), (16, False, False)])
+def test_batchnorm_other_types(C, relu, residual, dt):
+  native = _native()
+  dev = torch.device("cuda")
+  td = TORCH[dt]
+  P = 777
+  gen = torch.Generator(device="cpu").manual_seed(C + dt)
+  y = (torch.randn(P, C, generator=gen) * 1.5 + 0.4).to(td).to(dev)
+  res = torch.randn(P, C, generator=gen).to(td).to(dev) if residual else None
+  gamma = (torch.rand(C, generator=gen) + 0.5).to(dev)
+  beta = (torch.randn(C, generator=gen) * 0.3).to(dev)
+  mm = torch.zeros(C, device=dev)
+  mv = torch.ones(C, device=dev)
+  saved = torch.zeros(4 * C, device=dev)
+  ws = torch.zeros(native.ext().bn_workspace_floats(), device=dev)
+  z = torch.empty(P, C, dtype=td, device=dev)
+  mask = torch.zeros(round_up(P * C // 8, 4), dtype=torch.uint8, device=dev)
+  sp = saved.data_ptr()
+  native.run_op("bn_fwd_train", dict(
+      y=y.data_ptr(), res=res.data_ptr() if residual else None, z=z.data_ptr(),
+      gamma=gamma.data_ptr(), beta=beta.data_ptr(), mm=mm.data_ptr(), mv=mv.data_ptr(),
+      save_mean=sp, save_invstd=sp + 4 * C, scale=sp + 8 * C, shift=sp + 12 * C, ws=ws.data_ptr(),
+      fused_replicas=0, mask=mask.data_ptr() if relu else None, P=P, C=C, eps=1e-5, momentum=0.9,
+      relu=int(relu), dt=dt))
+  torch.cuda.synchronize()
+  yr = y.float().requires_grad_(True)
+  gr = gamma.clone().requires_grad_(True)
+  br = beta.clone().requires_grad_(True)
+  rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+  zr = F.batch_norm(yr, rm, rv, gr, br, True, 0.1, 1e-5)
+  if residual:
+    zr = zr + res.float()
+  if relu:
+    zr = torch.relu(zr)
+  tol = TOL[dt]
+  assert (z.float() - zr).abs().max().item() <= tol * 10 + tol * zr.abs().max().item()
+  assert torch.allclose(mm, rm, rtol=1e-4, atol=1e-5) and torch.allclose(mv, rv, rtol=1e-4, atol=1e-5)
+  # backward
+  dz = torch.randn(P, C, generator=gen).to(td).to(dev)
+  zr.backward(dz.float())
+  dgamma = torch.zeros(C, device=dev)
+  dbeta = torch.zeros(C, device=dev)
+  dyv = torch.empty(P, C, dtype=td, device=dev)
+  native.run_op("bn_bwd", dict(
+      dz=dz.data_ptr(), y=y.data_ptr(), z=None, mask=mask.data_ptr() if relu else None,
+      mean=sp, invstd=sp + 4 * C, gamma=gamma.data_ptr(), dgamma=dgamma.data_ptr(),
+      dbeta=dbeta.data_ptr(), dy=dyv.data_ptr(), dres=None, ws=ws.data_ptr(), P=P, C=C, dt=dt))
+  torch.cuda.synchronize()
+  rt = 5e-3 if dt == 2 else 3e-2      # fp32: the mask of elements at exactly 0 and sum order
+  assert torch.allclose(dgamma, gr.grad, rtol=rt, atol=rt * gr.grad.abs().max().item())
+  assert torch.allclose(dbeta, br.grad, rtol=rt, atol=rt * br.grad.abs().max().item())
+  assert (dyv.float() - yr.grad).abs().max().item() <= rt * yr.grad.abs().max().item() + 1e-4
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+def test_pooling_and_loss_other_types(dt):
+  native = _native()
+  dev = torch.device("cuda")
+  td = TORCH[dt]
+  gen = torch.Generator(device="cpu").manual_seed(dt)
+  N, H, W, C = 3, 13, 12, 64
+  x = torch.randn(N, H, W, C, generator=gen).to(td).to(dev)
+  pt, pb = same_padding(H, 3, 2)
+  pl, pr = same_padding(W, 3, 2)
+  OH, OW = (H + pt + pb - 3) // 2 + 1, (W + pl + pr - 3) // 2 + 1
+  out = torch.empty(N, OH, OW, C, dtype=td, device=dev)
+  idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device=dev)
+  geo = dict(N=N, H=H, W=W, C=C, OH=OH, OW=OW, k=3, stride=2, pt=pt, pl=pl, idx=idx.data_ptr(), dt=dt)
+  native.run_op("maxpool_fwd", dict(geo, x=x.data_ptr(), out=out.data_ptr()))
+  xr = x.float().requires_grad_(True)
+  ref = F.max_pool2d(F.pad(xr.permute(0, 3, 1, 2), (pl, pr, pt, pb), value=float("-inf")), 3, 2)
+  ref = ref.permute(0, 2, 3, 1)
+  torch.cuda.synchronize()
+  assert torch.equal(out.float(), ref.detach())
+  dy = torch.randn(N, OH, OW, C, generator=gen).to(td).to(dev)
+  ref.backward(dy.float())
+  dx = torch.empty(N, H, W, C, dtype=td, device=dev)
+  native.run_op("maxpool_bwd", dict(geo, dy=dy.data_ptr(), dx=dx.data_ptr()))
+  torch.cuda.synchronize()
+  assert torch.allclose(dx.float(), xr.grad, rtol=TOL[dt], atol=TOL[dt])
+  # global mean
+  m = torch.empty(N, C, dtype=td, device=dev)
+  native.run_op("mean_fwd", dict(x=x.data_ptr(), out=m.data_ptr(), N=N, HW=H * W, C=C, dt=dt))
+  torch.cuda.synchronize()
+  assert torch.allclose(m.float(), x.float().mean((1, 2)), rtol=TOL[dt], atol=TOL[dt])
+  # loss
+  Cc, ld = 1001, 1008
+  logits = torch.zeros(N, ld, dtype=td, device=dev)
+  logits[:, :Cc] = (torch.randn(N, Cc, generator=gen) * 3).to(td).to(dev)
+  labels = torch.randint(0, Cc, (N,), generator=gen).to(torch.int32).to(dev)
+  dl = torch.empty(N, ld, dtype=td, device=dev)
+  acc = torch.zeros(2, device=dev)
+  native.run_op("softmax_xent", dict(logits=logits.data_ptr(), labels=labels.data_ptr(),
+                                     dlogits=dl.data_ptr(), accum=acc.data_ptr(), N=N, C=Cc, ld=ld,
+                                     grad_scale=1.0 / N, dt=dt))
+  torch.cuda.synchronize()
+  lr = logits.float()[:, :Cc].requires_grad_(True)
+  loss = F.cross_entropy(lr, labels.long(), reduction="sum")
+  (loss / N).backward()
+  assert acc[0].item() == pytest.approx(loss.item(), rel=1e-4)
+  assert torch.allclose(dl.float()[:, :Cc], lr.grad, rtol=TOL[dt], atol=TOL[dt] * 1e-1)
+  assert float(dl[:, Cc:].abs().max()) == 0.0
+
+
+def _executors(spec, batch, dtype, packs=3):
+  from distributed_tensorflow_amd.engine.hip_executor import HipExecutor
+  from distributed_tensorflow_amd.engine.params import ParamStore
+  from distributed_tensorflow_amd.engine.torch_executor import TorchExecutor
+  dev = torch.device("cuda")
+  st_h, st_t = ParamStore(spec, dev, 7), ParamStore(spec, dev, 7)
+  hx = HipExecutor(spec, st_h, batch, dtype, st_h.make_buckets(packs), use_graph=False)
+  tx = TorchExecutor(spec, st_t, batch, "fp32", st_t.make_buckets(packs))
+  return hx, tx, st_h, st_t
+
+
+def _rel(a, b):
+  return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+@pytest.mark.parametrize("name,batch,bound", [("resnet20", 16, 1e-2), ("resnet50", 8, 8e-2)])
+def test_fp32_step_matches_pytorch_fp32_per_variable(name, batch, bound):
+  """The whole planned step in fp32 against PyTorch autograd in fp32: loss and forward statistics
+  to 1e-4, the gradient of *every* variable to the bound two correct fp32 implementations reach on
+  this problem.  That bound is loose for ResNet-50 at batch 8: the backward pass through 53
+  freshly initialised BatchNorm layers amplifies rounding differences, and PyTorch's own GPU and
+  CPU kernels disagree by 2-3 % per variable there (scripts/debug/debug_fp32_compare.py).  The
+  tight, per-layer check of the plan's wiring is tests/test_hip_teacher.py."""
+  spec = getattr(models, name)()
+  hx, tx, st_h, st_t = _executors(spec, batch, "fp32")
+  assert hx.dt == 2 and hx.acts[spec.logits_name].dtype == torch.float32
+  g = torch.Generator(device="cpu").manual_seed(3)
+  H, W, C = spec.input_shape
+  x = (torch.randn(batch, H, W, C, generator=g) * 60 + 120).cuda()
+  y = torch.randint(0, spec.num_classes, (batch,), generator=g).cuda()
+  lh, ch = hx.train_step(x, y, 1.0)
+  lt, ct = tx.train_step(x, y, 1.0)
+  torch.cuda.synchronize()
+  assert lh.item() == pytest.approx(lt.item(), rel=1e-4)
+  assert ch.item() == ct.item()
+  worst = ("", 0.0)
+  for e in st_h.trainable:
+    gh, gt = st_h.view(e.spec.name, "grad"), st_t.view(e.spec.name, "grad")
+    if gt.norm() < 1e-9:
+      continue
+    r = _rel(gh, gt)
+    if r > worst[1]:
+      worst = (e.spec.name, r)
+  assert worst[1] <= bound, worst
+  for e in st_h.non_trainable:
+    assert torch.allclose(st_h.view(e.spec.name), st_t.view(e.spec.name), rtol=1e-4, atol=1e-5), e.spec.name
+  # inference path (separate BatchNorm launches, no folding for this type)
+  le, ce = hx.eval_step(x, y)
+  lte, cte = tx.eval_step(x, y)
+  assert le.item() == pytest.approx(lte.item(), rel=1e-4)
+  p = hx.predict(x)
+  assert torch.allclose(p, tx.predict(x), rtol=1e-3, atol=1e-5)
+
+
+def test_fp16_step_with_loss_scale():
+  """fp16 storage with the reference's static loss scale (`get_loss_scale(..., 128)`): the scale
+  is applied in the loss gradient and removed by the optimizer's divisor; gradients agree with
+  fp32 PyTorch to half precision."""
+  spec = models.resnet20()
+  hx, tx, st_h, st_t = _executors(spec, 16, "fp16")
+  assert hx.dt == 1 and hx.acts[spec.logits_name].dtype == torch.float16
+  g = torch.Generator(device="cpu").manual_seed(4)
+  x = (torch.randn(16, 32, 32, 3, generator=g) * 60 + 120).cuda()
+  y = torch.randint(0, 10, (16,), generator=g).cuda()
+  lh, _ = hx.train_step(x, y, 128.0)
+  lt, _ = tx.train_step(x, y, 1.0)
+  torch.cuda.synchronize()
+  assert lh.item() == pytest.approx(lt.item(), rel=2e-2)
+  for e in st_h.trainable:
+    if e.spec.var not in ("kernel",):
+      continue
+    gh, gt = st_h.view(e.spec.name, "grad") / 128.0, st_t.view(e.spec.name, "grad")
+    assert torch.isfinite(gh).all()
+    assert _rel(gh, gt) < 0.3, e.spec.name
+
+
+def test_model_picks_the_native_engine_for_every_dtype():
+  from distributed_tensorflow_amd.train.model import Model
+  from distributed_tensorflow_amd.train.optimizers import SGD
+  dev = torch.device("cuda")
+  for dtype in ("fp32", "fp16", "bf16"):
+    m = Model(models.resnet20(), dtype=dtype, device=dev, seed=1)
+    assert m.executor_kind == "hip"
+    m.compile(SGD(0.05, momentum=0.9), "sparse_categorical_crossentropy",
+              ["sparse_categorical_accuracy"])
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = (torch.randn(8, 32, 32, 3, generator=g) * 50 + 100).to(dev)
+    y = torch.randint(0, 10, (8, 1), generator=g).float().to(dev)
+    losses = [m.train_on_batch(x, y)[0].item() for _ in range(6)]
+    assert losses[-1] < losses[0], (dtype, losses)
