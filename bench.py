@@ -49,7 +49,7 @@ def main() -> int:
   ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                   help="cpu: rehearsal of the launch / collective / reporting path without a GPU "
                        "(gloo, PyTorch-operator executor, fp32); not a benchmark")
-  ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"],
+  ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"],
                   help="compute precision (default: bf16 on the GPU, fp32 on the CPU)")
   ap.add_argument("--num_packs", type=int, default=4, help="gradient fusion buckets")
   ap.add_argument("--all_reduce_alg", default=None)

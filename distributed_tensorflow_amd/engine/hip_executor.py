@@ -44,6 +44,8 @@ __all__ = ["HipExecutor", "supports"]
 def supports(spec: ModelSpec) -> bool:
   """True when every op of the model has a native kernel path."""
   first = spec.ops[0] if spec.ops else None
+  if _is_mlp(spec):
+    return True           # flatten + dense chain: streamed by the kernels of dense.hip
   if first is None or first.kind != "conv" or first.inputs[0] != "input":
     return False          # the planner stages the input batch for a leading convolution
   for op in spec.ops:
@@ -56,6 +58,20 @@ def supports(spec: ModelSpec) -> bool:
       if c < 8 or c > 2048 or c & (c - 1):
         return False
   return True
+
+
+def _is_mlp(spec: ModelSpec) -> bool:
+  """Flatten followed by a chain of dense layers (the reference's trivial model,
+  `image_classification/trivial_model.py:26-41`), at most 4096 logits."""
+  ops = spec.ops
+  if len(ops) < 2 or ops[0].kind != "flatten" or ops[0].inputs[0] != "input":
+    return False
+  prev = ops[0].output
+  for op in ops[1:]:
+    if op.kind != "dense" or list(op.inputs) != [prev]:
+      return False
+    prev = op.output
+  return prev == spec.logits_name and spec.num_classes <= 4096
 
 
 class _TypedPlan:
@@ -136,7 +152,10 @@ class HipExecutor:
     self._pool_idx: Dict[str, torch.Tensor] = {}
     self._seen_version = -1
     with torch.cuda.device(self.device):
-      self._plan_model()
+      if _is_mlp(spec):
+        self._plan_mlp()
+      else:
+        self._plan_model()
 
   # ----------------------------------------------------------------------------------------
   # buffers
@@ -310,6 +329,95 @@ class HipExecutor:
     logging.info("HipExecutor planned %s for batch %d: %d fwd + %d bwd launches, %.2f GB of "
                  "buffers, %d gradient buckets", spec.name, N, self.fwd_plan.size(),
                  self.bwd_plan.size(), nbytes / 2 ** 30, len(self.buckets))
+
+  def _plan_mlp(self):
+    """Plan of a flatten + dense chain: every layer streams its fp32 master weights
+    (`dense.hip`), nothing is packed.  Forward: cast the staged images to the element type as
+    [N, H*W*C], one launch per layer, loss.  Backward, last layer first: weight gradient,
+    bias gradient (column sums), data gradient - plain stores into the zeroed flat buffer."""
+    spec, N = self.spec, self.N
+    H, W, C = spec.input_shape
+    self.images = self._alloc((N, H, W, C), torch.float32)
+    self.labels = self._alloc((N,), torch.int32)
+    self.accum = self._alloc((2,), torch.float32)
+    self.loss_scale_dev = self._alloc((1,), torch.float32)
+    self.loss_scale_dev.fill_(1.0)
+    self._loss_scale = 1.0
+    self.geoms, self._bn_lazy, self._bn_pool = {}, {}, {}
+    self._pack_args = None
+    acts: Dict[str, torch.Tensor] = {}
+    self.acts = acts
+    flat = spec.ops[0]
+    layers = spec.ops[1:]
+    K0 = H * W * C
+    acts["input"] = self.images
+    acts[flat.output] = self._alloc((N, K0))
+    for op in layers:
+      acts[op.output] = self._alloc((N, op.attrs["out_features"]))
+    ext = native.ext()
+    self.fwd_plan = _TypedPlan(ext.Plan(), self.dt)
+    self.eval_plan = _TypedPlan(ext.Plan(), self.dt)
+    self.bwd_plan = _TypedPlan(ext.Plan(), self.dt)
+    logits = acts[spec.logits_name]
+    self.dlogits = self._alloc(tuple(logits.shape))
+    for plan, training in ((self.fwd_plan, True), (self.eval_plan, False)):
+      plan.add("memset", dict(ptr=self.accum.data_ptr(), nbytes=8), "zero_loss")
+      plan.add("cast", {"in": self.images.data_ptr(), "out": acts[flat.output].data_ptr(),
+                        "n": N * K0}, flat.name)
+      for op in layers:
+        at = op.attrs
+        plan.add("dense_fwd", dict(x=acts[op.inputs[0]].data_ptr(), w=self._var_ptr(op.name + "/kernel"),
+                                   bias=self._var_ptr(op.name + "/bias"), out=acts[op.output].data_ptr(),
+                                   N=N, K=at["in_features"], Cout=at["out_features"]), op.name)
+      plan.add("softmax_xent", dict(
+          logits=logits.data_ptr(), labels=self.labels.data_ptr(),
+          dlogits=self.dlogits.data_ptr() if training else None, accum=self.accum.data_ptr(),
+          N=N, C=spec.num_classes, ld=logits.shape[1], grad_scale=1.0 / N,
+          grad_scale_dev=self.loss_scale_dev.data_ptr()), "softmax_xent")
+    # ---- backward ------------------------------------------------------------------------------
+    plan = self.bwd_plan
+    grads: Dict[str, torch.Tensor] = {spec.logits_name: self.dlogits}
+    self.act_grads = grads
+    var_bucket, remaining = {}, {}
+    for b in self.buckets:
+      remaining[b.index] = len(b.var_names)
+      for v in b.var_names:
+        var_bucket[v] = b.index
+    by_index = {b.index: b for b in self.buckets}
+    self._segments = []
+    seg_begin = 0
+    plan.add("memset", dict(ptr=self.store.grads.data_ptr(), nbytes=self.store.grads.numel() * 4),
+             "zero_grads")
+    for op in reversed(layers):
+      at = op.attrs
+      K, Co = at["in_features"], at["out_features"]
+      dy = grads[op.output]
+      x = acts[op.inputs[0]]
+      plan.add("dense_wgrad", dict(x=x.data_ptr(), dy=dy.data_ptr(),
+                                   dw=self._var_ptr(op.name + "/kernel", "grad"), N=N, K=K, Cout=Co),
+               op.name + "/wgrad")
+      plan.add("colsum", dict(x=dy.data_ptr(), out=self._var_ptr(op.name + "/bias", "grad"), N=N,
+                              C=Co, ld=Co), op.name + "/dbias")
+      if op is not layers[0]:
+        grads[op.inputs[0]] = self._alloc((N, K), zero=False)
+        plan.add("dense_dgrad", dict(dy=dy.data_ptr(), w=self._var_ptr(op.name + "/kernel"),
+                                     dx=grads[op.inputs[0]].data_ptr(), N=N, K=K, Cout=Co),
+                 op.name + "/dgrad")
+      ready = []
+      for v in (op.name + "/kernel", op.name + "/bias"):
+        bi = var_bucket[v]
+        remaining[bi] -= 1
+        if remaining[bi] == 0:
+          ready.append(by_index[bi])
+      if ready:
+        self._segments.append((seg_begin, plan.size(), ready))
+        seg_begin = plan.size()
+    if seg_begin != plan.size() or not self._segments:
+      self._segments.append((seg_begin, plan.size(), []))
+    self.probs = None
+    logging.info("HipExecutor planned %s for batch %d: %d fwd + %d bwd launches (dense streaming "
+                 "kernels), %d gradient buckets", spec.name, N, self.fwd_plan.size(),
+                 self.bwd_plan.size(), len(self.buckets))
 
   def _plan_weight_packing(self):
     """bf16 copies of every conv / dense kernel: forward layout and data-gradient layout."""
@@ -856,7 +964,8 @@ class HipExecutor:
   # ----------------------------------------------------------------------------------------
   def params_updated(self):
     """Refresh the packed bf16 weights from the fp32 master copy (one multi-tensor launch)."""
-    native.run_op("pack_weights", self._pack_args)
+    if self._pack_args is not None:      # dense-only plans read the master weights directly
+      native.run_op("pack_weights", self._pack_args)
     self._seen_version = self.store.version
 
   def _ensure_packed(self):
@@ -872,12 +981,14 @@ class HipExecutor:
     if labels is not None:
       self.labels.copy_(labels.reshape(-1), non_blocking=True)
 
-  def _set_loss_scale(self, s: float):
-    if s != self._loss_scale:
+  def _set_loss_scale(self, s: Optional[float]):
+    """None: the device-side scale is maintained by the loss-scale kernel of the optimizer."""
+    if s is not None and s != self._loss_scale:
       self.loss_scale_dev.fill_(float(s))
       self._loss_scale = float(s)
 
-  def train_step(self, images: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0,
+  def train_step(self, images: torch.Tensor, labels: torch.Tensor,
+                 loss_scale: Optional[float] = 1.0,
                  on_bucket_ready: Optional[Callable[[Bucket], None]] = None,
                  soft_joins: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """`soft_joins`: `on_bucket_ready` orders its work behind the side lane itself

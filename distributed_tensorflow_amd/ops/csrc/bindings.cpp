@@ -283,8 +283,39 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     const float lr = get_or<float>(d, "lr", 0.f), mom = get_or<float>(d, "momentum", 0.f);
     const float gs = get_or<float>(d, "grad_scale", 1.f);
     auto hyper = ptr<const float>(d, "hyper", false);   // device [lr, momentum, grad_scale]
+    auto skip = ptr<const float>(d, "skip", false);     // device [skip flag, inverse loss scale]
     const int um = get_or<int>(d, "use_momentum", mom != 0.f ? 1 : 0);
-    return [=](hipStream_t s) { launch_sgd_momentum_l2(p, g, v, l2, n, lr, mom, gs, um, hyper, s); };
+    return [=](hipStream_t s) { launch_sgd_momentum_l2(p, g, v, l2, n, lr, mom, gs, um, hyper, skip, s); };
+  }
+  if (kind == "dense_fwd") {
+    auto x = ptr<const void>(d, "x"); auto w = ptr<const float>(d, "w");
+    auto bias = ptr<const float>(d, "bias", false); auto out = ptr<void>(d, "out");
+    const int N = get<int>(d, "N"), K = get<int>(d, "K"), C = get<int>(d, "Cout");
+    const int ldx = get_or<int>(d, "ldx", K), ldo = get_or<int>(d, "ldo", C);
+    return [=](hipStream_t s) { launch_dense_fwd(x, w, bias, out, N, K, C, ldx, ldo, dt, s); };
+  }
+  if (kind == "dense_wgrad") {
+    auto x = ptr<const void>(d, "x"); auto dy = ptr<const void>(d, "dy"); auto dw = ptr<float>(d, "dw");
+    const int N = get<int>(d, "N"), K = get<int>(d, "K"), C = get<int>(d, "Cout");
+    const int ldx = get_or<int>(d, "ldx", K), ldy = get_or<int>(d, "ldy", C);
+    return [=](hipStream_t s) { launch_dense_wgrad(x, dy, dw, N, K, C, ldx, ldy, dt, s); };
+  }
+  if (kind == "dense_dgrad") {
+    auto dy = ptr<const void>(d, "dy"); auto w = ptr<const float>(d, "w"); auto dx = ptr<void>(d, "dx");
+    const int N = get<int>(d, "N"), K = get<int>(d, "K"), C = get<int>(d, "Cout");
+    const int ldy = get_or<int>(d, "ldy", C), ldx = get_or<int>(d, "ldx", K);
+    return [=](hipStream_t s) { launch_dense_dgrad(dy, w, dx, N, K, C, ldy, ldx, dt, s); };
+  }
+  if (kind == "nonfinite_flag") {
+    auto g = ptr<const float>(d, "g"); auto flag = ptr<unsigned int>(d, "flag");
+    const size_t n = get<size_t>(d, "n");
+    return [=](hipStream_t s) { launch_nonfinite_flag(g, n, flag, s); };
+  }
+  if (kind == "loss_scale_update") {
+    auto state = ptr<float>(d, "state"); auto flag = ptr<unsigned int>(d, "flag");
+    auto lsd = ptr<float>(d, "loss_scale_dev", false);
+    const float growth = get_or<float>(d, "growth", 2000.f), mult = get_or<float>(d, "multiplier", 2.f);
+    return [=](hipStream_t s) { launch_loss_scale_update(state, flag, lsd, growth, mult, s); };
   }
   if (kind == "pack_weights") {
     auto params = ptr<const float>(d, "params"); auto packed = ptr<void>(d, "packed");

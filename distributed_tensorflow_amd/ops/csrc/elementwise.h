@@ -64,9 +64,23 @@ void launch_softmax_probs(const void* logits, float* probs, int N, int C, int ld
                           hipStream_t s);
 void launch_colsum(const void* x, float* out, int N, int C, int ld, int dt, hipStream_t s);
 
+// Dense layers of any shape on fp32 master weights [in, out] (dense.hip).
+void launch_dense_fwd(const void* x, const float* w, const float* bias, void* out, int N, int K,
+                      int Cout, int ldx, int ldo, int dt, hipStream_t s);
+void launch_dense_wgrad(const void* x, const void* dy, float* dw, int N, int K, int Cout, int ldx,
+                        int ldy, int dt, hipStream_t s);
+void launch_dense_dgrad(const void* dy, const float* w, void* dx, int N, int K, int Cout, int ldy,
+                        int ldx, int dt, hipStream_t s);
+// Dynamic loss scaling without a host round trip (dense.hip): flag[0] |= any non-finite gradient;
+// the state kernel consumes the flag and updates [scale, clean, skipped, skip, 1/scale used];
+// the fused optimizer takes state + 3 as `skip` ([skip, inverse scale]).
+void launch_nonfinite_flag(const float* g, size_t n, unsigned int* flag, hipStream_t s);
+void launch_loss_scale_update(float* state, unsigned int* flag, float* loss_scale_dev, float growth,
+                              float multiplier, hipStream_t s);
+
 void launch_sgd_momentum_l2(float* p, const float* g, float* v, const float* l2x2, size_t n,
                             float lr, float momentum, float grad_scale, int use_momentum,
-                            const float* hyper, hipStream_t s);
+                            const float* hyper, const float* skip, hipStream_t s);
 
 // One entry per packed bf16 weight copy (see optim.hip).
 struct PackDesc {

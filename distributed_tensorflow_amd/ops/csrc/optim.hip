@@ -24,11 +24,19 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
                                                   const float* __restrict__ l2x2, size_t n4,
                                                   size_t n, float lr, float momentum,
                                                   float grad_scale, int use_momentum,
-                                                  const float* __restrict__ hyper) {
+                                                  const float* __restrict__ hyper,
+                                                  const float* __restrict__ skip) {
   if (hyper) {   // per-step scalars live in device memory so a captured graph sees new values
     lr = hyper[0];
     momentum = hyper[1];
     grad_scale = hyper[2];
+  }
+  // dynamic loss scaling, decided on the device (the host never looks): skip[0] != 0 - a
+  // non-finite gradient was found, the step is left out; skip[1] = 1 / (scale the gradients
+  // were produced with)
+  if (skip) {
+    if (skip[0] != 0.f) return;
+    grad_scale *= skip[1];
   }
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -178,12 +186,12 @@ inline int grid_for(size_t total) {
 
 void launch_sgd_momentum_l2(float* p, const float* g, float* v, const float* l2x2, size_t n,
                             float lr, float momentum, float grad_scale, int use_momentum,
-                            const float* hyper, hipStream_t s) {
+                            const float* hyper, const float* skip, hipStream_t s) {
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)v | (uintptr_t)l2x2) & 15)
     throw std::invalid_argument("sgd: buffers must be 16-byte aligned");
   const size_t n4 = n / 4;
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n4 ? n4 : 1)), dim3(256), 0, s, p, g, v, l2x2, n4, n,
-                     lr, momentum, grad_scale, use_momentum, hyper);
+                     lr, momentum, grad_scale, use_momentum, hyper, skip);
 }
 
 void launch_pack_weights(const float* params, void* packed, const PackDesc* descs, int ndesc,

@@ -17,7 +17,7 @@ except ImportError as e:                      # pragma: no cover - exercised onl
   _ext = None
   _import_error = e
 
-__all__ = ["available", "ext", "run_op", "Plan", "stream_handle", "sgd_momentum_l2",
+__all__ = ["available", "ext", "run_op", "Plan", "stream_handle", "sgd_momentum_l2", "loss_scale_step",
            "pack_desc_bytes", "pack_blocks", "PACK_PER_BLOCK"]
 
 PACK_PER_BLOCK = 256 * 8
@@ -49,7 +49,10 @@ def Plan():
 
 
 def sgd_momentum_l2(params: torch.Tensor, grads: torch.Tensor, velocity: torch.Tensor,
-                    l2x2: torch.Tensor, lr: float, momentum: float, grad_scale: float = 1.0):
+                    l2x2: torch.Tensor, lr: float, momentum: float, grad_scale: float = 1.0,
+                    skip: Optional[torch.Tensor] = None):
+  """`skip`: two device floats [skip flag, extra gradient factor] of a device-side loss-scale
+  state (`loss_scale_step`); flag != 0 leaves the update out."""
   for t in (params, grads, velocity, l2x2):
     if t.dtype != torch.float32 or not t.is_contiguous() or t.device != params.device:
       raise ValueError("sgd_momentum_l2 wants contiguous fp32 tensors on one device")
@@ -58,7 +61,23 @@ def sgd_momentum_l2(params: torch.Tensor, grads: torch.Tensor, velocity: torch.T
     raise ValueError("sgd_momentum_l2: buffer sizes differ")
   run_op("sgd", dict(p=params.data_ptr(), g=grads.data_ptr(), v=velocity.data_ptr(),
                      l2x2=l2x2.data_ptr(), n=n, lr=float(lr), momentum=float(momentum),
-                     grad_scale=float(grad_scale)))
+                     grad_scale=float(grad_scale),
+                     skip=skip.data_ptr() if skip is not None else None))
+
+
+def loss_scale_step(grads: torch.Tensor, state: torch.Tensor, flag: torch.Tensor,
+                    loss_scale_dev: Optional[torch.Tensor], growth: int, multiplier: float):
+  """Dynamic loss scaling without a host round trip: one pass over the flat gradients sets
+  `flag` when any element is inf / nan, then a one-thread kernel advances
+  state = [scale, clean steps, skipped steps, skip, 1 / scale used] and writes the next
+  step's scale to `loss_scale_dev` (the executor's loss-gradient factor)."""
+  if state.dtype != torch.float32 or state.numel() < 5 or flag.dtype != torch.int32:
+    raise ValueError("loss_scale_step: state is 5 floats, flag one int32")
+  run_op("nonfinite_flag", dict(g=grads.data_ptr(), n=grads.numel(), flag=flag.data_ptr()))
+  run_op("loss_scale_update", dict(
+      state=state.data_ptr(), flag=flag.data_ptr(),
+      loss_scale_dev=loss_scale_dev.data_ptr() if loss_scale_dev is not None else None,
+      growth=float(growth), multiplier=float(multiplier)))
 
 
 def pack_blocks(d: Dict) -> int:

@@ -188,8 +188,15 @@ class Model:
     return labels.reshape(-1).long()
 
   # -- one step ---------------------------------------------------------------------
-  def _loss_scale(self) -> float:
-    return self.optimizer.loss_scale if isinstance(self.optimizer, LossScaleOptimizer) else 1.0
+  def _loss_scale(self, executor=None) -> Optional[float]:
+    """Loss-gradient factor of the next step; None when the native engine's device-side scale
+    is already current (dynamic scaling decided on the GPU)."""
+    opt = self.optimizer
+    while not isinstance(opt, LossScaleOptimizer):     # e.g. hvd.DistributedOptimizer(LossScale(..))
+      opt = getattr(opt, "inner", None)
+      if opt is None:
+        return 1.0
+    return opt.loss_scale_for(executor) if executor is not None else opt.loss_scale
 
   def train_on_batch(self, images: torch.Tensor, labels: torch.Tensor):
     """Runs one optimisation step; returns (mean loss tensor, correct-count tensor)."""
@@ -210,10 +217,10 @@ class Model:
     red = self._grad_reducer()
     if red is not None and getattr(ex, "native", False) and \
         getattr(red, "orders_side_lane", None) is not None and red.orders_side_lane(ex):
-      loss, correct = ex.train_step(images, idx, self._loss_scale(), red.on_bucket_ready,
+      loss, correct = ex.train_step(images, idx, self._loss_scale(ex), red.on_bucket_ready,
                                     soft_joins=True)
     else:
-      loss, correct = ex.train_step(images, idx, self._loss_scale(),
+      loss, correct = ex.train_step(images, idx, self._loss_scale(ex),
                                     red.on_bucket_ready if red is not None else None)
     if red is not None:
       red.finish()

@@ -79,12 +79,14 @@ class SGD(Optimizer):
     self.momentum = float(momentum)
 
   def apply_gradients(self, store: ParamStore, grad_divisor: float = 1.0,
-                      executor=None) -> bool:
+                      executor=None, skip=None) -> bool:
+    """`skip`: device floats [skip flag, extra gradient factor] of a device-side loss-scale
+    state; the kernel leaves the update out when the flag is set."""
     lr = self.current_lr()
     from ..ops import fused  # pylint: disable=import-outside-toplevel
     v = store.slot("momentum") if self.momentum else store.params  # unused when momentum == 0
     fused.sgd_momentum_l2(store.params, store.grads, v, store.l2_vector(), lr,
-                          self.momentum, 1.0 / grad_divisor)
+                          self.momentum, 1.0 / grad_divisor, skip)
     store.version += 1
     if executor is not None:
       executor.params_updated()
@@ -105,11 +107,17 @@ class LossScaleOptimizer(Optimizer):
                multiplier: float = 2.0):
     self.inner = inner
     self.dynamic = loss_scale == "dynamic"
+    self._dev_state = None
     self.scale = float(initial_scale if self.dynamic else loss_scale)
     self.growth_steps = growth_steps
     self.multiplier = multiplier
     self._good_steps = 0
-    self.skipped_steps = 0
+    self._skipped = 0
+    # device-side state of dynamic scaling on the native engine:
+    # [scale, clean steps, skipped steps, skip this step, 1 / scale of this step's gradients]
+    self._dev_state: Optional[torch.Tensor] = None
+    self._dev_flag: Optional[torch.Tensor] = None
+    self._bound = None       # the executor whose device-side scale the state kernel maintains
 
   # learning-rate plumbing goes to the wrapped optimizer
   @property
@@ -142,17 +150,62 @@ class LossScaleOptimizer(Optimizer):
     return self.inner.current_lr()
 
   @property
+  def scale(self) -> float:
+    """Current loss scale (reads the device state back when scaling runs on the device)."""
+    if self._dev_state is not None:
+      return float(self._dev_state[0].item())
+    return self._scale
+
+  @scale.setter
+  def scale(self, v: float):
+    self._scale = float(v)
+    if self._dev_state is not None:
+      self._dev_state[0] = float(v)
+
+  @property
+  def skipped_steps(self) -> int:
+    if self._dev_state is not None:
+      return int(self._dev_state[2].item())
+    return self._skipped
+
+  @property
   def loss_scale(self) -> float:
     return self.scale
 
+  def loss_scale_for(self, executor) -> Optional[float]:
+    """The factor for the next step's loss gradient on `executor`; None: it already sits in
+    that executor's device-side scale (`loss_scale_dev`), written by the scaling kernel of the
+    previous step.  Another executor (a different batch size) gets the value read back."""
+    if self._dev_state is not None and executor is self._bound:
+      return None
+    return self.scale
+
+  def _apply_on_device(self, store: ParamStore, grad_divisor: float, executor) -> bool:
+    """Native engine: finiteness pass, scale state machine and the skip decision all run on
+    the GPU - two small launches in front of the fused optimizer, no `.item()` per step."""
+    from ..ops import native  # pylint: disable=import-outside-toplevel
+    if self._dev_state is None:
+      dev = store.grads.device
+      self._dev_state = torch.tensor([self._scale, float(self._good_steps), float(self._skipped),
+                                      0.0, 1.0], dtype=torch.float32, device=dev)
+      self._dev_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    native.loss_scale_step(store.grads, self._dev_state, self._dev_flag,
+                           executor.loss_scale_dev, self.growth_steps, self.multiplier)
+    self._bound = executor
+    executor._loss_scale = None     # its host-side copy of the scale is stale from here on
+    return self.inner.apply_gradients(store, grad_divisor, executor, skip=self._dev_state[3:5])
+
   def apply_gradients(self, store: ParamStore, grad_divisor: float = 1.0,
                       executor=None) -> bool:
+    if (self.dynamic and store.grads.device.type == "cuda"
+        and getattr(executor, "loss_scale_dev", None) is not None):
+      return self._apply_on_device(store, grad_divisor, executor)
     if self.dynamic:
       finite = bool(torch.isfinite(store.grads).all().item())
       if not finite:
         self.scale = max(self.scale / self.multiplier, 1.0)
         self._good_steps = 0
-        self.skipped_steps += 1
+        self._skipped += 1
         return False
     ok = self.inner.apply_gradients(store, grad_divisor * self.scale, executor)
     if self.dynamic:

@@ -341,8 +341,12 @@ def define_performance(num_parallel_calls=False, inter_op=True, intra_op=True,
                    "Stop training after this many global steps.", "mts")
   if dtype:
     DEFINE_enum("dtype", "fp32", ["fp16", "bf16", "fp32"],
-                "Compute precision. Variables are always kept in fp32. bf16 is the "
-                "native MI355X mixed-precision mode; fp16 adds loss scaling.", "dt")
+                "Storage type of activations and packed weights; variables, accumulation and "
+                "statistics are always fp32.  fp32 (the reference's default): exact fp32 matrix "
+                "instructions.  fp16 (the reference's mixed precision): IEEE half with loss "
+                "scaling.  bf16: the type the MI355X engine is tuned for (fused statistics, "
+                "multi-stage pipelines), no loss scaling needed.  All three run on the native "
+                "kernels on a GPU.", "dt")
     if loss_scale:
       DEFINE_string("loss_scale", None,
                     "Loss scale for reduced-precision training: a positive number, or "

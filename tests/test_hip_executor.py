@@ -327,19 +327,136 @@ def test_native_engine_learns_a_separable_task_like_the_reference_executor():
   assert results["hip"][1] > 0.95, results
 
 
-def test_model_without_native_plan_falls_back_to_pytorch_ops_on_the_gpu():
-  """`--use_trivial_model --dtype fp16` on a GPU (`resnet_imagenet_main.py:189-191`): Flatten ->
-  Dense(1) -> Dense has nothing for the native planner, so `executor="auto"` runs it with
-  PyTorch ops, while an explicit `executor="hip"` still refuses."""
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_trivial_model_runs_on_the_native_engine(dtype):
+  """`--use_trivial_model` on a GPU (`resnet_imagenet_main.py:189-191`): Flatten -> Dense(1) ->
+  Dense(1001) is planned with the streaming dense kernels; losses, logits and every gradient agree
+  with PyTorch autograd in fp32, and a model the planner has nothing for still falls back."""
+  from distributed_tensorflow_amd.engine.hip_executor import HipExecutor
+  from distributed_tensorflow_amd.engine.params import ParamStore
   from distributed_tensorflow_amd.train.model import Model
   dev = torch.device("cuda")
   spec = models.trivial_model(1001)
+  m = Model(spec, dtype=dtype, device=dev)
+  assert m.executor_kind == "hip"
+  N = 8
+  store = ParamStore(spec, dev, 3)
+  hx = HipExecutor(spec, store, N, dtype, store.make_buckets(2), use_graph=False)
+  g = torch.Generator().manual_seed(4)
+  x = torch.randn(N, 224, 224, 3, generator=g).to(dev)
+  y = torch.randint(0, 1001, (N,), generator=g).to(dev)
+  seen = []
+  loss, _ = hx.train_step(x, y, 1.0, on_bucket_ready=lambda b: seen.append(b.index))
+  assert sorted(seen) == sorted(b.index for b in hx.buckets)
+  # fp32 reference on what the engine saw (inputs rounded to the element type)
+  xr = x.reshape(N, -1).to(hx.act_dtype).float()
+  w0 = store.view("dense/kernel").clone().requires_grad_(True)
+  b0 = store.view("dense/bias").clone().requires_grad_(True)
+  w1 = store.view("dense_1/kernel").clone().requires_grad_(True)
+  b1 = store.view("dense_1/bias").clone().requires_grad_(True)
+  h = xr @ w0 + b0
+  if dtype != "fp32":
+    h = h + (h.detach().to(hx.act_dtype).float() - h.detach())     # stored rounded
+  logits = h @ w1 + b1
+  ref = torch.nn.functional.cross_entropy(logits, y)
+  ref.backward()
+  tol = 1e-4 if dtype == "fp32" else 2e-2
+  assert abs(loss.item() - ref.item()) <= tol * max(1.0, abs(ref.item()))
+  for name, p in (("dense/kernel", w0), ("dense/bias", b0), ("dense_1/kernel", w1), ("dense_1/bias", b1)):
+    got = store.view(name, "grad")
+    rel = ((got - p.grad).norm() / p.grad.norm().clamp_min(1e-12)).item()
+    assert rel <= (1e-4 if dtype == "fp32" else 3e-2), (name, rel)
+  # eval and predict run the same plan
+  l2, _ = hx.eval_step(x, y)
+  assert abs(l2.item() - loss.item()) <= 1e-5 * max(1.0, abs(loss.item()))
+  probs = hx.predict(x)
+  assert torch.allclose(probs.sum(1), torch.ones(N, device=dev), atol=1e-3)
+  # end to end through Model: the loss falls on a fixed batch
+  m.compile(SGD(0.01, momentum=0.9), "sparse_categorical_crossentropy", ["sparse_categorical_accuracy"])
+  xs = torch.randn(4, 224, 224, 3, device=dev)
+  ys = torch.randint(0, 1001, (4, 1), device=dev).float()
+  first = m.train_on_batch(xs, ys)[0].item()
+  for _ in range(5):
+    last = m.train_on_batch(xs, ys)[0].item()
+  assert last < first
+
+
+def test_model_without_native_plan_falls_back_to_pytorch_ops_on_the_gpu():
+  """A model with an op the native planner has no kernel for (here: a dense layer fed by a
+  pooled feature map whose width is not a multiple of 8) runs with PyTorch ops under
+  `executor="auto"`, while an explicit `executor="hip"` refuses."""
+  from distributed_tensorflow_amd.models.graph import GraphBuilder
+  from distributed_tensorflow_amd.train.model import Model
+  dev = torch.device("cuda")
+  g = GraphBuilder("odd", (8, 8, 3), 10)
+  t = g.conv("input", "conv", 12, 3, 1, "same")
+  t = g.global_mean(t)
+  t = g.dense(t, "fc", 10, out="logits")
+  spec = g.build(t)
   m = Model(spec, dtype="bf16", device=dev)
   assert m.executor_kind == "torch"
   m.compile(SGD(0.01, momentum=0.9), "sparse_categorical_crossentropy", ["sparse_categorical_accuracy"])
-  x = torch.randn(4, 224, 224, 3, device=dev)
-  y = torch.randint(0, 1001, (4, 1), device=dev).float()
+  x = torch.randn(4, 8, 8, 3, device=dev)
+  y = torch.randint(0, 10, (4, 1), device=dev).float()
   loss, _ = m.train_on_batch(x, y)
   assert torch.isfinite(loss).item()
   with pytest.raises(ValueError):
     Model(spec, dtype="bf16", device=dev, executor="hip")._executor(4)
+
+
+def test_dynamic_loss_scale_is_decided_on_the_device():
+  """Dynamic loss scaling on the native engine (`resnet_imagenet_main.py:182-187`): finiteness
+  pass, scale state machine and the skip of the update run as kernels in front of the fused
+  optimizer.  Same results as the host-side state machine: a clean step equals the host path's
+  step, a non-finite gradient leaves parameters and momentum untouched and halves the scale,
+  `growth_steps` clean steps double it, and the executor's loss-gradient factor follows."""
+  from distributed_tensorflow_amd.engine.hip_executor import HipExecutor
+  from distributed_tensorflow_amd.engine.params import ParamStore
+  from distributed_tensorflow_amd.train.optimizers import LossScaleOptimizer
+  dev = torch.device("cuda")
+  spec = models.resnet20()
+  N = 8
+  g = torch.Generator().manual_seed(2)
+  x = (torch.randn(N, 32, 32, 3, generator=g)).to(dev)
+  y = torch.randint(0, 10, (N,), generator=g).to(dev)
+
+  def make():
+    store = ParamStore(spec, dev, 5)
+    store.slot("momentum")
+    return store, HipExecutor(spec, store, N, "fp16", store.make_buckets(1), use_graph=False)
+
+  sa, ea = make()
+  sb, eb = make()
+  dyn_dev = LossScaleOptimizer(SGD(0.1, momentum=0.9), "dynamic", initial_scale=1024.0, growth_steps=3)
+  dyn_host = LossScaleOptimizer(SGD(0.1, momentum=0.9), "dynamic", initial_scale=1024.0, growth_steps=3)
+  # step 1: clean on both paths
+  ea.train_step(x, y, dyn_dev.loss_scale_for(ea))
+  eb.train_step(x, y, dyn_host.loss_scale_for(eb))
+  assert dyn_dev.apply_gradients(sa, 1.0, ea)
+  assert dyn_host.apply_gradients(sb, 1.0, None)         # no executor: the host state machine
+  eb.params_updated()
+  assert dyn_dev._dev_state is not None and dyn_host._dev_state is None
+  assert torch.allclose(sa.params, sb.params, rtol=0, atol=1e-7)
+  assert dyn_dev.loss_scale_for(ea) is None               # the device-side scale is current
+  # step 2: a non-finite gradient
+  before = sa.params.clone()
+  vel = sa.slot("momentum").clone()
+  ea.train_step(x, y, dyn_dev.loss_scale_for(ea))
+  sa.grads[12345] = float("inf")
+  dyn_dev.apply_gradients(sa, 1.0, ea)
+  assert torch.equal(sa.params, before) and torch.equal(sa.slot("momentum"), vel)
+  assert dyn_dev.skipped_steps == 1 and dyn_dev.scale == 512.0
+  assert ea.loss_scale_dev.item() == 512.0
+  sa.grads[12345] = float("nan")
+  dyn_dev.apply_gradients(sa, 1.0, ea)
+  assert torch.equal(sa.params, before) and dyn_dev.skipped_steps == 2 and dyn_dev.scale == 256.0
+  # three clean steps double the scale; the gradients of each are divided by the scale they
+  # were produced with
+  for i in range(3):
+    ea.train_step(x, y, dyn_dev.loss_scale_for(ea))
+    assert torch.isfinite(sa.grads).all()
+    dyn_dev.apply_gradients(sa, 1.0, ea)
+  assert dyn_dev.scale == 512.0 and ea.loss_scale_dev.item() == 512.0
+  assert not torch.equal(sa.params, before)
+  # another executor (different batch size) is handed the value
+  assert dyn_dev.loss_scale_for(eb) == 512.0

@@ -16,8 +16,9 @@ the stored gradient of its output - and compared with what the plan left behind:
 Tensors the plan never materialises (the normalised shortcut of a projection block, the stem's
 full-resolution activation, masked residual gradients) are recomputed from their producers /
 consumers the same way.  Errors do not accumulate across layers, so the bounds are tight:
-1e-3 relative L2 in fp32 (a ReLU mask bit that flips at a pre-activation within rounding of zero
-moves a BatchNorm gradient by a few 1e-4), 1e-2 in bf16 (one rounding of the stored result).
+5e-3 relative L2 in fp32 (each ReLU mask bit that flips at a pre-activation within rounding of
+zero moves a gradient tensor of a million elements by about 1e-3 of its norm; a wiring mistake
+moves it by its whole norm), 1e-2 in bf16 (one rounding of the stored result).
 """
 import pytest
 import torch
@@ -129,7 +130,7 @@ class _Teacher:
 
 
 @pytest.mark.parametrize("name,batch,dtype,tol", [
-    ("resnet20", 16, "fp32", 1e-3), ("resnet50", 8, "fp32", 1e-3),
+    ("resnet20", 16, "fp32", 5e-3), ("resnet50", 8, "fp32", 5e-3),
     ("resnet20", 16, "bf16", 1e-2), ("resnet50", 8, "bf16", 1e-2),
 ])
 def test_every_layer_backward_from_the_executors_own_buffers(name, batch, dtype, tol):
