@@ -16,21 +16,48 @@ control plane is a FIFO mailbox per PS rank kept in the rendezvous TCP store:
     PS k:    waits for "ps<k>/req/<head>", serves it, head += 1
 
 which gives any-source, first-come-first-served service without deadlock: a PS
-only ever posts a transfer that the requesting worker is about to post too.
+only ever posts a transfer that the requesting worker posts too, and a worker
+posts its transfers in the order of its requests.
 
-Ops: `pull` (PS -> worker: parameter shard, PS 0 also BatchNorm moving
-statistics), `push:<lr>:<divisor>` (worker -> PS: gradient shard, to PS 0 also
-moving statistics; the PS runs the fused SGD-momentum+L2 update on its shard
-with the learning rate the worker's schedule computed), `done` (worker is
-finished; a PS returns once every worker said so - a clean shutdown instead of
-`pkill`).
+Requests:
+
+* `pull:<rank>:<fmt>` - PS -> worker: the parameter shard as fp32 or bfloat16
+  (a 16-bit worker would round the fp32 values the same way itself; half the
+  bytes), PS 0 also the BatchNorm moving statistics.
+* `push:<rank>:<lr>:<divisor>:<fmt>:<lo>-<hi>,...` - worker -> PS: the gradient
+  shard as pieces (one per gradient bucket that intersects the shard, in the
+  order the backward pass completes them), fp32 or bfloat16; to PS 0 also the
+  moving statistics; last a one-element trailer: 1 = apply, 0 = the worker found
+  a non-finite gradient (dynamic loss scaling), drop it.
+* `done:<rank>` - the worker is finished; a PS returns once every worker said so
+  (a clean shutdown instead of `pkill`).
+
+Overlap.  A worker's step is
+
+    wait for the prefetched parameters -> request the *next* step's parameters
+    -> forward / backward, every gradient bucket leaving as soon as it is complete
+    -> trailer
+
+with the transfers on two lane threads (one receiving, one sending, each a FIFO)
+so that the host thread only enqueues: the next parameters arrive while this
+step computes (they miss this step's own update: staleness + 1, on top of the
+staleness asynchronous SGD has anyway; `DTF_PS_PREFETCH=0` restores strict
+pull -> compute -> push), and all but the last bucket of the push is hidden
+behind the backward pass.  The PS posts the receives of a push and moves on: up
+to two pushes are in flight into two buffers while it serves other requests, and
+a complete push is applied with one fused SGD-momentum+L2 launch over the shard.
+With RCCL a posted receive occupies the communicator's stream, so there a worker
+announces its push only when the whole gradient is ready and the PS completes
+each push before it takes the next request.
 """
 from __future__ import annotations
 
+import collections
+import concurrent.futures
 import datetime
 import os
 import time
-from typing import List, Optional, Tuple
+from typing import Deque, Dict, List, Optional, Tuple
 
 import torch
 
@@ -81,7 +108,20 @@ class ParameterServerStrategy(Strategy):
     self._store = comm.store() if comm.world_size > 1 else None
     self._done_sent = False
     self.updates_applied = 0
-    self._host = {}
+    self.updates_dropped = 0
+    self._host: Dict = {}
+    self.prefetch = os.environ.get("DTF_PS_PREFETCH", "1") != "0"
+    # gradients travel as bfloat16 when the worker computes in a 16-bit type, unless told otherwise
+    self.push_dtype = os.environ.get("DTF_PS_PUSH_DTYPE", "auto").lower()
+    # a posted receive is free with gloo and blocks the communicator's stream with RCCL
+    self.stream_push = comm.backend != "nccl"
+    self._recv_lane = concurrent.futures.ThreadPoolExecutor(1, thread_name_prefix="ps-recv")
+    self._send_lane = concurrent.futures.ThreadPoolExecutor(1, thread_name_prefix="ps-send")
+    self._prefetched = None        # (future, fmt) of the parameters requested ahead
+    self._push: Optional[Dict] = None
+    self._last_send = None         # future of the previous step's last transfer
+    self._copy_stream = None
+    self._h2d_done = None
 
   # -- topology --------------------------------------------------------------------
   @property
@@ -130,79 +170,263 @@ class ParameterServerStrategy(Strategy):
       pass
     return msg
 
-  # -- transfers ---------------------------------------------------------------------
+  def _request_waiting(self, ps: int, head: int) -> bool:
+    try:
+      return bool(self._store.check(["ps%d/req/%d" % (ps, head)]))
+    except Exception:  # pragma: no cover - a store without check(): behave as if busy
+      return True
+
+  # -- buffers -----------------------------------------------------------------------
   # RCCL moves device memory directly.  Any other backend (gloo: parameter server in host
   # memory like the reference's `/job:ps/.../CPU:0`, or a rehearsal on fewer GPUs than ranks)
   # gets device tensors staged through pinned host buffers here: gloo's own handling of device
   # tensors took seconds for the 102 MB of ResNet-50 on the test machine.
-  def _staging(self, t: torch.Tensor) -> Optional[torch.Tensor]:
-    if not t.is_cuda or self.comm.backend == "nccl":
-      return None
-    key = (t.numel(), t.dtype)
-    buf = self._host.get(key)
-    if buf is None:
-      buf = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
-      self._host[key] = buf
-    return buf
+  def _staged(self, device) -> bool:
+    return torch.device(device).type == "cuda" and self.comm.backend != "nccl"
 
-  def _send(self, t: torch.Tensor, dst: int):
-    h = self._staging(t)
-    if h is None:
-      self.comm.send(t, dst)
-    else:
-      h.copy_(t.reshape(-1))             # synchronous device-to-host copy
-      self.comm.send(h, dst)
+  def _buf(self, tag, n: int, dtype, device=None, pinned=False) -> torch.Tensor:
+    key = (tag, n, dtype, str(device), pinned)
+    if key not in self._host:
+      if pinned:
+        self._host[key] = torch.empty(max(n, 1), dtype=dtype, pin_memory=True)
+      else:
+        self._host[key] = torch.empty(max(n, 1), dtype=dtype, device=device)
+    return self._host[key]
 
-  def _recv(self, t: torch.Tensor, src: int):
-    h = self._staging(t)
-    if h is None:
-      self.comm.recv(t, src)
-    else:
-      self.comm.recv(h, src)
-      t.reshape(-1).copy_(h, non_blocking=False)
+  def _stream(self, device):
+    if self._copy_stream is None:
+      self._copy_stream = torch.cuda.Stream(device)
+    return self._copy_stream
 
   # -- worker side -------------------------------------------------------------------
   def _shards(self, store):
     return shard_ranges(store.num_elements, self.num_ps)
 
-  def pull(self, store, half: bool = False):
-    """Fetch the current parameters (and moving statistics) from the PS ranks.
+  def _start_pull(self, store, fmt: str):
+    """Posts the pull requests and queues the receives on the receiving lane; returns the
+    future of the lane task, whose result is the list of filled landing buffers."""
+    dtype = torch.bfloat16 if fmt == "bf16" else torch.float32
+    shards = self._shards(store)
+    dev = store.device
+    staged = self._staged(dev)
+    for k in range(self.num_ps):
+      self._post(k, "pull:%d:%s" % (self.comm.rank, fmt))
+    h2d_done = self._h2d_done
+
+    def task():
+      if dev.type == "cuda":
+        torch.cuda.set_device(dev)
+      if h2d_done is not None:
+        h2d_done.synchronize()       # the previous pull has left the pinned landing buffers
+      out = []
+      for k, (a, b) in enumerate(shards):
+        land = None
+        if b > a:
+          land = self._buf(("pull", k), b - a, dtype, None if staged else dev, pinned=staged)
+          self.comm.recv(land[:b - a], k)
+        state = None
+        if k == 0 and store.num_state_elements:
+          state = self._buf("pull_state", store.num_state_elements, torch.float32,
+                            None if staged else dev, pinned=staged)
+          self.comm.recv(state[:store.num_state_elements], 0)
+        out.append((a, b, land, state))
+      return out
+
+    return self._recv_lane.submit(task)
+
+  def pull(self, store, half: bool = False, fresh: bool = False):
+    """Leaves the PS ranks' parameters (and moving statistics) in `store`.
 
     `half`: the worker computes in a 16-bit format, so it asks for bfloat16 parameters - half
     the bytes per pull, and exactly the values its executor would round the fp32 ones to.  The
-    master copy stays fp32 on the PS (updates are applied there)."""
-    for k, (a, b) in enumerate(self._shards(store)):
-      self._post(k, "pull:%d:%s" % (self.comm.rank, "bf16" if half else "fp32"))
-    for k, (a, b) in enumerate(self._shards(store)):
-      if b > a and half:
-        buf = self._half_buf(b - a, store.device)
-        self._recv(buf, k)
-        store.params[a:b].copy_(buf)
-      elif b > a:
-        self._recv(store.params[a:b], k)
-      if k == 0 and store.num_state_elements:
-        self._recv(store.state, 0)
+    master copy stays fp32 on the PS (updates are applied there).  Parameters requested ahead by
+    the previous step are used when there are any; `fresh` discards them, waits until this
+    worker's own pushes have left and asks again (evaluation, checkpoints)."""
+    fmt = "bf16" if half else "fp32"
+    pre, self._prefetched = self._prefetched, None
+    if pre is not None and (fresh or pre[1] != fmt):
+      pre[0].result()            # the PS is sending it anyway: receive and drop
+      pre = None
+    if pre is None:
+      if self._last_send is not None:
+        self._last_send.result()
+      pre = (self._start_pull(store, fmt), fmt)
+    landed = pre[0].result()
+    dev = store.device
+    for a, b, land, state in landed:
+      if land is not None:
+        if land.device != dev:       # pinned host -> device, then widen on the device
+          tmp = self._buf("pull_dev", b - a, land.dtype, dev)
+          tmp[:b - a].copy_(land[:b - a], non_blocking=True)
+          land = tmp
+        store.params[a:b].copy_(land[:b - a])
+      if state is not None:
+        store.state.copy_(state[:store.num_state_elements], non_blocking=True)
+    if self._staged(dev):
+      self._h2d_done = torch.cuda.Event()
+      self._h2d_done.record()
     store.version += 1
 
-  def _half_buf(self, n: int, device) -> torch.Tensor:
-    key = ("half", n, str(device))
-    if key not in self._host:
-      self._host[key] = torch.empty(n, dtype=torch.bfloat16, device=device)
-    return self._host[key]
+  def begin_push(self, store, buckets, lr: float, divisor: float = 1.0, half: bool = False):
+    """Announces this step's gradient push (and the next step's pull) before the backward pass;
+    `on_bucket_ready` then hands each finished bucket to the sending lane."""
+    if self._last_send is not None:
+      self._last_send.result()      # the previous push has left the gradient / staging buffers
+      self._last_send = None
+    if self.prefetch:
+      self._prefetched = (self._start_pull(store, "bf16" if half else "fp32"),
+                          "bf16" if half else "fp32")
+    fmt = self.push_dtype
+    if fmt not in ("bf16", "fp32"):
+      fmt = "bf16" if half else "fp32"
+    order = sorted(buckets, key=lambda bk: bk.index)
+    pieces: List[List[Tuple[int, int]]] = []       # per PS: element ranges in sending order
+    for a, b in self._shards(store):
+      pieces.append([(max(a, bk.start), min(b, bk.end)) for bk in order
+                     if min(b, bk.end) > max(a, bk.start)])
+    self._push = dict(store=store, fmt=fmt, order=order, pieces=pieces, next=0, ready={},
+                      lr=float(lr), divisor=float(divisor), posted=False, works=[], keep=[])
+    if self.stream_push:
+      self._post_push()
 
-  def push(self, store, lr: float, divisor: float = 1.0):
-    """Send this worker's gradients; the PS applies them on arrival."""
-    for k, (a, b) in enumerate(self._shards(store)):
-      self._post(k, "push:%d:%r:%r" % (self.comm.rank, float(lr), float(divisor)))
-    for k, (a, b) in enumerate(self._shards(store)):
-      if b > a:
-        self._send(store.grads[a:b], k)
-      if k == 0 and store.num_state_elements:
-        self._send(store.state, 0)
+  def _post_push(self):
+    p = self._push
+    shards = self._shards(p["store"])
+    for k, (a, _b) in enumerate(shards):
+      self._post(k, "push:%d:%r:%r:%s:%s" % (
+          self.comm.rank, p["lr"], p["divisor"], p["fmt"],
+          ",".join("%d-%d" % (lo - a, hi - a) for lo, hi in p["pieces"][k])))
+    p["posted"] = True
+
+  def on_bucket_ready(self, bucket):
+    """Called by the executor when the kernels that complete `bucket` have been enqueued."""
+    p = self._push
+    ev = None
+    if p["store"].device.type == "cuda":
+      ev = torch.cuda.Event()
+      ev.record()
+    p["ready"][bucket.index] = ev
+    # buckets leave strictly in the announced order
+    while p["next"] < len(p["order"]) and p["order"][p["next"]].index in p["ready"]:
+      bk = p["order"][p["next"]]
+      p["next"] += 1
+      if self.stream_push:
+        self._queue_bucket(p, bk, p["ready"][bk.index])
+
+  def _queue_bucket(self, p, bk, ev):
+    store, fmt = p["store"], p["fmt"]
+    dev = store.device
+    staged = self._staged(dev)
+    dtype = torch.bfloat16 if fmt == "bf16" else torch.float32
+    shards = self._shards(store)
+    n = store.num_elements
+
+    def task():
+      src = store.grads
+      if dev.type == "cuda":
+        torch.cuda.set_device(dev)
+        stream = self._stream(dev)
+        with torch.cuda.stream(stream):
+          if ev is not None:
+            stream.wait_event(ev)
+          if fmt == "bf16":
+            half = self._buf("push_half", n, dtype, dev)
+            half[bk.start:bk.end].copy_(store.grads[bk.start:bk.end])
+            src = half
+          if staged:
+            host = self._buf("push_host", n, dtype, None, pinned=True)
+            host[bk.start:bk.end].copy_(src[bk.start:bk.end], non_blocking=True)
+            src = host
+            stream.synchronize()
+          for k, (a, b) in enumerate(shards):
+            lo, hi = max(a, bk.start), min(b, bk.end)
+            if hi > lo:
+              p["works"].append(self.comm.isend(src[lo:hi], k))
+        return
+      if fmt == "bf16":
+        src = store.grads[bk.start:bk.end].to(dtype)
+        p["keep"].append(src)
+        for k, (a, b) in enumerate(shards):
+          lo, hi = max(a, bk.start), min(b, bk.end)
+          if hi > lo:
+            p["works"].append(self.comm.isend(src[lo - bk.start:hi - bk.start], k))
+        return
+      for k, (a, b) in enumerate(shards):
+        lo, hi = max(a, bk.start), min(b, bk.end)
+        if hi > lo:
+          p["works"].append(self.comm.isend(src[lo:hi], k))
+
+    self._last_send = self._send_lane.submit(task)
+
+  def end_push(self, finite: bool = True):
+    """After the step: whatever has not left yet, the moving statistics (to PS 0) and the
+    trailer that tells every PS whether to apply this push."""
+    p = self._push
+    store = p["store"]
+    dev = store.device
+    ev = None
+    if dev.type == "cuda":
+      ev = torch.cuda.Event()
+      ev.record()
+    if not self.stream_push:
+      self._post_push()                       # RCCL: announced only now, sent in one go
+      for bk in p["order"]:
+        self._queue_bucket(p, bk, ev)
+    else:
+      while p["next"] < len(p["order"]):      # an executor that never called back
+        self._queue_bucket(p, p["order"][p["next"]], ev)
+        p["next"] += 1
+    staged = self._staged(dev)
+    flag = 1.0 if finite else 0.0
+
+    def task():
+      state = store.state
+      trailer = torch.full((1,), flag, dtype=torch.float32, device="cpu" if staged else dev)
+      if dev.type == "cuda":
+        torch.cuda.set_device(dev)
+        if ev is not None:
+          ev.synchronize()
+        if staged and store.num_state_elements:
+          host = self._buf("push_state", store.num_state_elements, torch.float32, None, pinned=True)
+          host.copy_(store.state)
+          state = host
+      works = p["works"]
+      for k in range(self.num_ps):
+        if k == 0 and store.num_state_elements:
+          works.append(self.comm.isend(state[:store.num_state_elements], 0))
+        works.append(self.comm.isend(trailer, k))
+      # The sends to different PS ranks are independent of each other (none of them is waited
+      # for before all are posted): a PS that is busy completing another worker's push cannot
+      # hold up what this worker owes to the other PS ranks, which rules out a cycle of waits
+      # across several PS ranks and workers.
+      for w in works:
+        w.wait()
+      p["keep"].clear()
+
+    self._last_send = self._send_lane.submit(task)
+    self._push = None
+
+  def push(self, store, lr: float, divisor: float = 1.0, buckets=None, half: bool = False,
+           finite: bool = True):
+    """The whole gradient in one call (no overlap with a backward pass); returns when it has
+    left."""
+    from ..engine.params import Bucket  # pylint: disable=import-outside-toplevel
+    keep, self.prefetch = self.prefetch, False
+    try:
+      self.begin_push(store, buckets or [Bucket(0, 0, store.num_elements, [])], lr, divisor, half)
+    finally:
+      self.prefetch = keep
+    self.end_push(finite)
+    self._last_send.result()
 
   def shutdown(self):
     if self.is_ps_task or self._done_sent or self._store is None:
       return
+    if self._prefetched is not None:          # the PS is sending it: take delivery
+      self._prefetched[0].result()
+      self._prefetched = None
+    if self._last_send is not None:
+      self._last_send.result()
     for k in range(self.num_ps):
       self._post(k, "done:%d" % self.comm.rank)
     self._done_sent = True
@@ -215,44 +439,113 @@ class ParameterServerStrategy(Strategy):
     k = self.task.task_index
     a, b = self._shards(store)[k]
     n = b - a
-    recv_buf = torch.zeros(max(n, 1), dtype=torch.float32, device=store.device)
+    dev = store.device
+    staged = self._staged(dev)
     shard = _ShardView(store, a, b)
+    has_state = k == 0 and store.num_state_elements > 0
+    ns = store.num_state_elements
     head = 0
     active = self.num_workers
-    logging.info("parameter server %d/%d serving shard [%d, %d) for %d workers",
-                 k, self.num_ps, a, b, active)
+    inflight: Deque[Dict] = collections.deque()
+    free_slots = [1, 0]
+    logging.info("parameter server %d/%d serving shard [%d, %d) for %d workers (%s%s)",
+                 k, self.num_ps, a, b, active, self.comm.backend,
+                 ", host-staged" if staged else "")
     t0 = time.time()
-    while active > 0:
+
+    def land(tag, slot, count, dtype):
+      return self._buf((tag, slot), count, dtype, None if staged else dev, pinned=staged)
+
+    def finalize(p):
+      for w in p["works"]:
+        w.wait()
+      if p["trailer"][0].item() != 0:
+        if n:
+          g = p["grads"]
+          if g.device != dev:
+            tmp = self._buf("ps_dev", n, g.dtype, dev)
+            tmp[:n].copy_(g[:n], non_blocking=True)
+            g = tmp
+          if g.dtype != torch.float32:
+            wide = self._buf("ps_f32", n, torch.float32, dev)
+            wide[:n].copy_(g[:n])
+            g = wide
+          shard.apply_sgd(g[:n], p["lr"], getattr(opt, "momentum", 0.0), p["divisor"])
+        if has_state:
+          store.state.copy_(p["state"][:ns], non_blocking=True)
+        if staged:
+          torch.cuda.current_stream(dev).synchronize()     # the landing buffers are free again
+        self.updates_applied += 1
+      else:
+        self.updates_dropped += 1
+      free_slots.append(p["slot"])
+
+    while active > 0 or inflight:
+      if inflight and (active == 0 or not self._request_waiting(k, head)):
+        finalize(inflight.popleft())          # nothing else to do: complete the oldest push
+        continue
       msg = self._next_request(k, head)
       head += 1
       parts = msg.split(":")
       op, src = parts[0], int(parts[1])
       if op == "pull":
-        if n and len(parts) > 2 and parts[2] == "bf16":
-          buf = self._half_buf(n, store.device)
-          buf.copy_(store.params[a:b])
-          self._send(buf, src)
-        elif n:
-          self._send(store.params[a:b], src)
-        if k == 0 and store.num_state_elements:
-          self._send(store.state, src)
+        # read-your-writes for the requesting worker; other workers' pushes are applied first
+        # only when they have arrived completely
+        for p in list(inflight):
+          if p["src"] == src or all(w.is_completed() for w in p["works"]):
+            inflight.remove(p)
+            finalize(p)
+        dtype = torch.bfloat16 if (len(parts) > 2 and parts[2] == "bf16") else torch.float32
+        if n:
+          out = store.params[a:b]
+          if dtype != torch.float32:
+            half = self._buf("serve_half", n, dtype, dev)
+            half[:n].copy_(out)
+            out = half[:n]
+          if staged:
+            host = self._buf("serve_host", n, dtype, None, pinned=True)
+            host[:n].copy_(out)                # synchronous device-to-host copy
+            out = host[:n]
+          self.comm.send(out, src)
+        if has_state:
+          st = store.state
+          if staged:
+            st = self._buf("serve_state", ns, torch.float32, None, pinned=True)
+            st[:ns].copy_(store.state)
+          self.comm.send(st[:ns], src)
       elif op == "push":
+        if not free_slots:
+          finalize(inflight.popleft())
+        slot = free_slots.pop()
         lr, divisor = float(parts[2]), float(parts[3])
-        if n:
-          self._recv(recv_buf[:n], src)
-        if k == 0 and store.num_state_elements:
-          self._recv(store.state, src)
-        if n:
-          shard.apply_sgd(recv_buf[:n], lr, getattr(opt, "momentum", 0.0), divisor)
-        self.updates_applied += 1
+        dtype = torch.bfloat16 if parts[4] == "bf16" else torch.float32
+        grads = land("ps_land", slot, n, dtype)
+        works = []
+        for piece in (parts[5].split(",") if parts[5] else []):
+          lo, hi = (int(v) for v in piece.split("-"))
+          if not 0 <= lo < hi <= n:
+            raise RuntimeError("parameter server: bad piece %s in %r" % (piece, msg))
+          works.append(self.comm.irecv(grads[lo:hi], src))
+        state = None
+        if has_state:
+          state = land("ps_state", slot, ns, torch.float32)
+          works.append(self.comm.irecv(state[:ns], src))
+        trailer = torch.zeros(1, dtype=torch.float32, device="cpu" if staged else dev)
+        works.append(self.comm.irecv(trailer, src))
+        p = dict(src=src, slot=slot, lr=lr, divisor=divisor, grads=grads, state=state,
+                 trailer=trailer, works=works)
+        if self.stream_push:
+          inflight.append(p)
+        else:
+          finalize(p)
       elif op == "done":
         active -= 1
       else:
         raise RuntimeError("parameter server: bad request %r" % msg)
     if store.device.type == "cuda":
       torch.cuda.synchronize(store.device)
-    logging.info("parameter server %d: %d updates applied in %.1f s; all workers done",
-                 k, self.updates_applied, time.time() - t0)
+    logging.info("parameter server %d: %d updates applied, %d dropped in %.1f s; all workers done",
+                 k, self.updates_applied, self.updates_dropped, time.time() - t0)
     return self.updates_applied
 
   def barrier(self):

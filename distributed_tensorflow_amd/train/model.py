@@ -45,6 +45,11 @@ def _next_batch(it, what: str, step: int, steps: int):
 SUPPORTED_LOSSES = ("sparse_categorical_crossentropy", "categorical_crossentropy")
 
 
+# executor kind of the most recently constructed Model ("hip" / "torch"): lets a driver-level test
+# or a log reader tell which engine a run used
+LAST_EXECUTOR_KIND: Optional[str] = None
+
+
 def _pick_executor_kind(requested: str, device: torch.device, dtype: str,
                         spec: Optional[ModelSpec] = None) -> str:
   """auto: the native engine on a GPU, PyTorch ops on the CPU.
@@ -89,6 +94,8 @@ class Model:
     self.data_format = data_format
     self.store = ParamStore(spec, self.device, seed)
     self.executor_kind = _pick_executor_kind(executor, self.device, self.dtype, spec)
+    global LAST_EXECUTOR_KIND  # pylint: disable=global-statement
+    LAST_EXECUTOR_KIND = self.executor_kind
     self._executors: Dict[int, object] = {}
     self.optimizer: Optional[Optimizer] = None
     self.loss: Optional[str] = None
@@ -191,12 +198,16 @@ class Model:
   def _loss_scale(self, executor=None) -> Optional[float]:
     """Loss-gradient factor of the next step; None when the native engine's device-side scale
     is already current (dynamic scaling decided on the GPU)."""
-    opt = self.optimizer
-    while not isinstance(opt, LossScaleOptimizer):     # e.g. hvd.DistributedOptimizer(LossScale(..))
-      opt = getattr(opt, "inner", None)
-      if opt is None:
-        return 1.0
+    opt = self._loss_scale_optimizer()
+    if opt is None:
+      return 1.0
     return opt.loss_scale_for(executor) if executor is not None else opt.loss_scale
+
+  def _loss_scale_optimizer(self) -> Optional[LossScaleOptimizer]:
+    opt = self.optimizer
+    while opt is not None and not isinstance(opt, LossScaleOptimizer):
+      opt = getattr(opt, "inner", None)      # e.g. hvd.DistributedOptimizer(LossScaleOptimizer(..))
+    return opt
 
   def train_on_batch(self, images: torch.Tensor, labels: torch.Tensor):
     """Runs one optimisation step; returns (mean loss tensor, correct-count tensor)."""
@@ -207,11 +218,22 @@ class Model:
     idx = self._class_indices(labels.to(self.device))
     if st is not None and not st.synchronous:
       # asynchronous parameter server: pull -> compute -> push
-      st.pull(self.store, half=self.dtype in ("bf16", "fp16"))
+      # (the next step's parameters are requested before this step computes, and every
+      # gradient bucket leaves while the backward pass is still running)
+      half = self.dtype in ("bf16", "fp16")
+      st.pull(self.store, half=half)
       ex.params_updated()
       scale = self._loss_scale()
-      loss, correct = ex.train_step(images, idx, scale)
-      st.push(self.store, self.optimizer.current_lr(), scale)
+      st.begin_push(self.store, self._bucket_list(), self.optimizer.current_lr(), scale, half)
+      loss, correct = ex.train_step(images, idx, scale, st.on_bucket_ready)
+      finite = True
+      ls = self._loss_scale_optimizer()
+      if ls is not None and ls.dynamic:
+        # the PS applies a push only when its trailer says so: a non-finite gradient is
+        # dropped there and the scale adapts here, as in the synchronous path
+        finite = bool(torch.isfinite(self.store.grads).all().item())
+        ls.update_scale(finite)
+      st.end_push(finite)
       self.optimizer.iterations += 1
       return loss, correct
     red = self._grad_reducer()
@@ -362,7 +384,7 @@ class Model:
     if st is not None and st.is_ps_task:
       return None
     if st is not None and not st.synchronous:
-      st.pull(self.store)
+      st.pull(self.store, fresh=True)
       for ex in self._executors.values():
         ex.params_updated()
     self._sync_initial_variables()

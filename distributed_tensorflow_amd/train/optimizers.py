@@ -195,24 +195,31 @@ class LossScaleOptimizer(Optimizer):
     executor._loss_scale = None     # its host-side copy of the scale is stale from here on
     return self.inner.apply_gradients(store, grad_divisor, executor, skip=self._dev_state[3:5])
 
+  def update_scale(self, finite: bool):
+    """Advances the host-side state machine by one step whose gradients were / were not finite
+    (used directly by the parameter-server worker, whose update is applied elsewhere)."""
+    if not self.dynamic:
+      return
+    if not finite:
+      self.scale = max(self.scale / self.multiplier, 1.0)
+      self._good_steps = 0
+      self._skipped += 1
+      return
+    self._good_steps += 1
+    if self._good_steps >= self.growth_steps:
+      self.scale *= self.multiplier
+      self._good_steps = 0
+
   def apply_gradients(self, store: ParamStore, grad_divisor: float = 1.0,
                       executor=None) -> bool:
     if (self.dynamic and store.grads.device.type == "cuda"
         and getattr(executor, "loss_scale_dev", None) is not None):
       return self._apply_on_device(store, grad_divisor, executor)
-    if self.dynamic:
-      finite = bool(torch.isfinite(store.grads).all().item())
-      if not finite:
-        self.scale = max(self.scale / self.multiplier, 1.0)
-        self._good_steps = 0
-        self._skipped += 1
-        return False
+    if self.dynamic and not bool(torch.isfinite(store.grads).all().item()):
+      self.update_scale(False)
+      return False
     ok = self.inner.apply_gradients(store, grad_divisor * self.scale, executor)
-    if self.dynamic:
-      self._good_steps += 1
-      if self._good_steps >= self.growth_steps:
-        self.scale *= self.multiplier
-        self._good_steps = 0
+    self.update_scale(True)
     return ok
 
   def get_config(self):

@@ -336,6 +336,65 @@ save(out)
   assert any(abs(r["psum"] - res[0]["psum"]) < 1e-6 * abs(res[0]["psum"]) for r in res[1:])
 
 
+@pytest.mark.parametrize("num_ps,workers,fmt", [(1, 7, "fp32"), (2, 6, "bf16")])
+def test_parameter_server_many_workers_no_deadlock_no_lost_update(tmp_path, num_ps, workers, fmt):
+  """The reference's shape of job (`ps_server/run.sh`: 1 ps + 15 workers) at 8 ranks: every
+  worker steps four times with overlapped pulls and bucket-wise pushes (three gradient buckets
+  split over the ps shards, fp32 or bfloat16 on the wire, one push of one worker carrying a
+  non-finite gradient).  Nothing deadlocks, every ps rank applies exactly one update per
+  finite push and drops the other, and the shards a worker reads back afterwards are the ps
+  ranks' copies."""
+  body = COMMON + """
+os.environ["DTF_PS_PUSH_DTYPE"] = %r
+strat = S.get_distribution_strategy("parameter_server", num_gpus=0)
+strat.num_packs = 3
+from distributed_tensorflow_amd.train.optimizers import LossScaleOptimizer
+m = Model(models.resnet20(), strategy=strat, dtype="fp32", seed=11)
+opt = LossScaleOptimizer(SGD(0.01, momentum=0.9), "dynamic", initial_scale=8.0)
+m.compile(opt, "sparse_categorical_crossentropy", ["sparse_categorical_accuracy"])
+out = {"ps": strat.is_ps_task}
+if strat.is_ps_task:
+  strat.serve(m)
+  out.update(applied=strat.updates_applied, dropped=strat.updates_dropped,
+             shard=list(strat._shards(m.store)[strat.task.task_index]),
+             params=m.store.params.double().sum().item())
+  a, b = out["shard"]
+  out["shard_sum"] = m.store.params[a:b].double().sum().item()
+else:
+  w = strat.worker_index
+  xs, ys = X[w:w + 2], Y[w:w + 2]
+  for step in range(4):
+    if w == 1 and step == 2:
+      xs = xs * float("inf")              # this worker's third gradient is not finite
+    l, c = m.train_on_batch(xs, ys)
+    if w == 1 and step == 2:
+      xs = X[w:w + 2]
+  out["scale"] = opt.scale
+  out["skipped"] = opt.skipped_steps
+  out["buckets"] = len(m._bucket_list())
+  # wait until every worker is done pushing, then read the ps copies back
+  st = strat._store
+  st.add("test/finished", 1)
+  import time
+  while int(st.add("test/finished", 0)) < strat.num_workers:
+    time.sleep(0.05)
+  strat.pull(m.store, fresh=True)
+  out["sums"] = [m.store.params[a:b].double().sum().item() for a, b in strat._shards(m.store)]
+  strat.shutdown()
+save(out)
+""" % fmt
+  res = _run_ranks(tmp_path, body, num_ps + workers, num_ps=num_ps, timeout=600)
+  ps, wk = res[:num_ps], res[num_ps:]
+  assert all(r["ps"] for r in ps) and not any(r["ps"] for r in wk)
+  for r in ps:
+    assert r["applied"] == 4 * workers - 1 and r["dropped"] == 1
+  assert all(r["buckets"] >= 3 for r in wk)
+  assert wk[1]["skipped"] == 1 and wk[1]["scale"] == 4.0 and wk[0]["scale"] == 8.0
+  for r in wk:
+    for k, want in enumerate(ps):
+      assert abs(r["sums"][k] - want["shard_sum"]) <= 1e-9 * max(1.0, abs(want["shard_sum"]))
+
+
 def test_launcher_fail_fast(tmp_path):
   body = """
 import time

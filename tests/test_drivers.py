@@ -255,3 +255,41 @@ def test_imagenet_fp16_flag_runs_native_engine_with_loss_scale(tmp_path, small_v
       extra_flags=["-batch_size", "16", "-train_steps", "4", "-num_gpus", "1", "-dtype", "fp16",
                    "-distribution_strategy", "off", "-log_steps", "1"], max_train=None)
   assert 0 < stats["loss"] < 20
+
+
+@pytest.mark.gpu
+def test_default_fp32_flag_runs_the_native_engine(tmp_path, small_validation):
+  """The reference's default precision (`--dtype` unset = fp32, `resnet_imagenet_main.py:97-100`)
+  trains and evaluates ResNet-50 on the native engine with exact fp32 matrix instructions -
+  not on PyTorch ops."""
+  resnet_imagenet_main.define_imagenet_keras_flags()
+  stats = integration.run_synthetic(
+      main=resnet_imagenet_main.run, tmp_root=str(tmp_path),
+      extra_flags=["-batch_size", "16", "-train_steps", "3", "-num_gpus", "1",
+                   "-distribution_strategy", "off", "-log_steps", "1"], max_train=None)
+  assert 0 < stats["loss"] < 20 and "eval_loss" in stats
+  from distributed_tensorflow_amd.train import model as model_mod
+  assert model_mod.LAST_EXECUTOR_KIND == "hip"
+
+
+@pytest.mark.gpu
+def test_fp16_dynamic_loss_scale_and_trivial_model_on_the_native_engine(tmp_path, small_validation):
+  """`--dtype fp16 --loss_scale dynamic` (device-side scaling) and `--use_trivial_model`."""
+  (tmp_path / "a").mkdir()
+  (tmp_path / "b").mkdir()
+  resnet_imagenet_main.define_imagenet_keras_flags()
+  stats = integration.run_synthetic(
+      main=resnet_imagenet_main.run, tmp_root=str(tmp_path / "a"),
+      extra_flags=["-batch_size", "16", "-train_steps", "4", "-num_gpus", "1", "-dtype", "fp16",
+                   "-loss_scale", "dynamic", "-distribution_strategy", "off", "-skip_eval"],
+      max_train=None)
+  assert 0 < stats["loss"] < 20
+  resnet_imagenet_main.define_imagenet_keras_flags()
+  stats = integration.run_synthetic(
+      main=resnet_imagenet_main.run, tmp_root=str(tmp_path / "b"),
+      extra_flags=["-batch_size", "16", "-train_steps", "4", "-num_gpus", "1", "-dtype", "fp16",
+                   "-use_trivial_model", "-distribution_strategy", "off", "-skip_eval"],
+      max_train=None)
+  assert "loss" in stats
+  from distributed_tensorflow_amd.train import model as model_mod
+  assert model_mod.LAST_EXECUTOR_KIND == "hip"
