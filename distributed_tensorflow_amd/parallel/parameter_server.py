@@ -111,6 +111,9 @@ class ParameterServerStrategy(Strategy):
     self.updates_dropped = 0
     self._host: Dict = {}
     self.prefetch = os.environ.get("DTF_PS_PREFETCH", "1") != "0"
+    # gradient buckets of this size leave while the backward pass is still running; what is
+    # left for after the step is the small tail bucket of the first layers
+    self.bucket_bytes = int(float(os.environ.get("DTF_PS_BUCKET_MB", "16")) * (1 << 20))
     # gradients travel as bfloat16 when the worker computes in a 16-bit type, unless told otherwise
     self.push_dtype = os.environ.get("DTF_PS_PUSH_DTYPE", "auto").lower()
     # a posted receive is free with gloo and blocks the communicator's stream with RCCL
@@ -122,6 +125,20 @@ class ParameterServerStrategy(Strategy):
     self._last_send = None         # future of the previous step's last transfer
     self._copy_stream = None
     self._h2d_done = None
+    # gloo moves one message with one progress thread per process group (2.5 GB/s on the test
+    # host, and no faster in both directions at once); transfers are therefore striped over
+    # several groups, half of them for each direction (51 MB each way: 40.7 -> 20.5 ms with 4)
+    nch = int(os.environ.get("DTF_PS_CHANNELS", "1" if comm.backend == "nccl" else "4"))
+    self._channels: List[List] = [[None], [None]]      # per direction: process groups
+    if comm.world_size > 1 and nch > 1:
+      import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+      groups = [dist.new_group(ranks=list(range(comm.world_size)), backend=comm.backend)
+                for _ in range(nch)]
+      self._channels = [groups[0::2], groups[1::2]]
+    # seconds the training thread spent waiting for transfers: what is *not* hidden
+    self.wait_s = {"pull": 0.0, "push": 0.0, "steps": 0, "gpu_ms": 0.0, "host_s": 0.0}
+    self._step_events = None
+    self._t_begin = None
 
   # -- topology --------------------------------------------------------------------
   @property
@@ -176,6 +193,28 @@ class ParameterServerStrategy(Strategy):
     except Exception:  # pragma: no cover - a store without check(): behave as if busy
       return True
 
+  # -- striped transfers ---------------------------------------------------------------
+  STRIPE_MIN = 1 << 17           # elements: smaller messages travel whole on the first channel
+
+  def _stripes(self, t: torch.Tensor, direction: int):
+    groups = self._channels[direction]
+    n = t.numel()
+    if len(groups) == 1 or n < self.STRIPE_MIN:
+      return [(t, groups[0])]
+    per = -(-n // len(groups))
+    per = -(-per // 8) * 8
+    return [(t[i * per:min(n, (i + 1) * per)], g) for i, g in enumerate(groups) if i * per < n]
+
+  def _isend(self, t: torch.Tensor, dst: int, direction: int) -> List:
+    import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+    return [dist.isend(c, dst, group=g) for c, g in self._stripes(t, direction)]
+
+  def _irecv(self, t: torch.Tensor, src: int, direction: int) -> List:
+    import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+    return [dist.irecv(c, src, group=g) for c, g in self._stripes(t, direction)]
+
+  PULL, PUSH = 0, 1              # directions: PS -> worker, worker -> PS
+
   # -- buffers -----------------------------------------------------------------------
   # RCCL moves device memory directly.  Any other backend (gloo: parameter server in host
   # memory like the reference's `/job:ps/.../CPU:0`, or a rehearsal on fewer GPUs than ranks)
@@ -211,24 +250,39 @@ class ParameterServerStrategy(Strategy):
     staged = self._staged(dev)
     for k in range(self.num_ps):
       self._post(k, "pull:%d:%s" % (self.comm.rank, fmt))
-    h2d_done = self._h2d_done
+    consumed = self._h2d_done
 
     def task():
       if dev.type == "cuda":
         torch.cuda.set_device(dev)
-      if h2d_done is not None:
-        h2d_done.synchronize()       # the previous pull has left the pinned landing buffers
+      if consumed is not None:
+        consumed.synchronize()       # the previous pull has been copied out of the landing buffers
       out = []
       for k, (a, b) in enumerate(shards):
-        land = None
+        land, works = None, []
         if b > a:
           land = self._buf(("pull", k), b - a, dtype, None if staged else dev, pinned=staged)
-          self.comm.recv(land[:b - a], k)
+          works = self._irecv(land[:b - a], k, self.PULL)
         state = None
         if k == 0 and store.num_state_elements:
           state = self._buf("pull_state", store.num_state_elements, torch.float32,
                             None if staged else dev, pinned=staged)
-          self.comm.recv(state[:store.num_state_elements], 0)
+          works += self._irecv(state[:store.num_state_elements], 0, self.PULL)
+        for w in works:
+          w.wait()
+        if staged and land is not None:
+          # host -> device on the copy stream, behind the compute of the running step: the
+          # training thread finds the parameters in device memory
+          stream = self._stream(dev)
+          with torch.cuda.stream(stream):
+            tmp = self._buf(("pull_dev", k), b - a, land.dtype, dev)
+            tmp[:b - a].copy_(land[:b - a], non_blocking=True)
+            if state is not None:
+              stmp = self._buf("pull_state_dev", store.num_state_elements, torch.float32, dev)
+              stmp.copy_(state[:store.num_state_elements], non_blocking=True)
+              state = stmp
+          stream.synchronize()
+          land = tmp
         out.append((a, b, land, state))
       return out
 
@@ -251,15 +305,13 @@ class ParameterServerStrategy(Strategy):
       if self._last_send is not None:
         self._last_send.result()
       pre = (self._start_pull(store, fmt), fmt)
+    t0 = time.time()
     landed = pre[0].result()
+    self.wait_s["pull"] += time.time() - t0
     dev = store.device
     for a, b, land, state in landed:
       if land is not None:
-        if land.device != dev:       # pinned host -> device, then widen on the device
-          tmp = self._buf("pull_dev", b - a, land.dtype, dev)
-          tmp[:b - a].copy_(land[:b - a], non_blocking=True)
-          land = tmp
-        store.params[a:b].copy_(land[:b - a])
+        store.params[a:b].copy_(land[:b - a])       # device to device, widening bf16
       if state is not None:
         store.state.copy_(state[:store.num_state_elements], non_blocking=True)
     if self._staged(dev):
@@ -271,8 +323,18 @@ class ParameterServerStrategy(Strategy):
     """Announces this step's gradient push (and the next step's pull) before the backward pass;
     `on_bucket_ready` then hands each finished bucket to the sending lane."""
     if self._last_send is not None:
+      t0 = time.time()
       self._last_send.result()      # the previous push has left the gradient / staging buffers
+      self.wait_s["push"] += time.time() - t0
       self._last_send = None
+    self.wait_s["steps"] += 1
+    if self._step_events is not None:       # complete by now: the sends waited for the GPU
+      self.wait_s["gpu_ms"] += self._step_events[0].elapsed_time(self._step_events[1])
+      self._step_events = None
+    if store.device.type == "cuda":
+      self._step_events = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+      self._step_events[0].record()
+    self._t_begin = time.time()
     if self.prefetch:
       self._prefetched = (self._start_pull(store, "bf16" if half else "fp32"),
                           "bf16" if half else "fp32")
@@ -341,7 +403,7 @@ class ParameterServerStrategy(Strategy):
           for k, (a, b) in enumerate(shards):
             lo, hi = max(a, bk.start), min(b, bk.end)
             if hi > lo:
-              p["works"].append(self.comm.isend(src[lo:hi], k))
+              p["works"] += self._isend(src[lo:hi], k, self.PUSH)
         return
       if fmt == "bf16":
         src = store.grads[bk.start:bk.end].to(dtype)
@@ -349,12 +411,12 @@ class ParameterServerStrategy(Strategy):
         for k, (a, b) in enumerate(shards):
           lo, hi = max(a, bk.start), min(b, bk.end)
           if hi > lo:
-            p["works"].append(self.comm.isend(src[lo - bk.start:hi - bk.start], k))
+            p["works"] += self._isend(src[lo - bk.start:hi - bk.start], k, self.PUSH)
         return
       for k, (a, b) in enumerate(shards):
         lo, hi = max(a, bk.start), min(b, bk.end)
         if hi > lo:
-          p["works"].append(self.comm.isend(src[lo:hi], k))
+          p["works"] += self._isend(src[lo:hi], k, self.PUSH)
 
     self._last_send = self._send_lane.submit(task)
 
@@ -365,9 +427,11 @@ class ParameterServerStrategy(Strategy):
     store = p["store"]
     dev = store.device
     ev = None
+    self.wait_s["host_s"] += time.time() - self._t_begin
     if dev.type == "cuda":
       ev = torch.cuda.Event()
       ev.record()
+      self._step_events[1].record()
     if not self.stream_push:
       self._post_push()                       # RCCL: announced only now, sent in one go
       for bk in p["order"]:
@@ -393,8 +457,8 @@ class ParameterServerStrategy(Strategy):
       works = p["works"]
       for k in range(self.num_ps):
         if k == 0 and store.num_state_elements:
-          works.append(self.comm.isend(state[:store.num_state_elements], 0))
-        works.append(self.comm.isend(trailer, k))
+          works += self._isend(state[:store.num_state_elements], 0, self.PUSH)
+        works += self._isend(trailer, k, self.PUSH)
       # The sends to different PS ranks are independent of each other (none of them is waited
       # for before all are posted): a PS that is busy completing another worker's push cannot
       # hold up what this worker owes to the other PS ranks, which rules out a cycle of waits
@@ -430,6 +494,12 @@ class ParameterServerStrategy(Strategy):
     for k in range(self.num_ps):
       self._post(k, "done:%d" % self.comm.rank)
     self._done_sent = True
+    n = max(self.wait_s["steps"], 1)
+    logging.info("parameter-server worker %d: %d steps, per step %.2f ms waiting for parameters, "
+                 "%.2f ms for the previous push to leave, %.2f ms enqueueing the step, %.2f ms of "
+                 "GPU time from its first to its last kernel", self.worker_index,
+                 self.wait_s["steps"], 1e3 * self.wait_s["pull"] / n, 1e3 * self.wait_s["push"] / n,
+                 1e3 * self.wait_s["host_s"] / n, self.wait_s["gpu_ms"] / n)
 
   # -- PS side ---------------------------------------------------------------------
   def serve(self, model) -> int:
@@ -456,35 +526,25 @@ class ParameterServerStrategy(Strategy):
     def land(tag, slot, count, dtype):
       return self._buf((tag, slot), count, dtype, None if staged else dev, pinned=staged)
 
+    busy = {"recv_wait": 0.0, "apply": 0.0, "pull_stage": 0.0, "pull_send": 0.0, "idle": 0.0}
+
     def finalize(p):
+      t1 = time.time()
       for w in p["works"]:
         w.wait()
-      if p["trailer"][0].item() != 0:
-        if n:
-          g = p["grads"]
-          if g.device != dev:
-            tmp = self._buf("ps_dev", n, g.dtype, dev)
-            tmp[:n].copy_(g[:n], non_blocking=True)
-            g = tmp
-          if g.dtype != torch.float32:
-            wide = self._buf("ps_f32", n, torch.float32, dev)
-            wide[:n].copy_(g[:n])
-            g = wide
-          shard.apply_sgd(g[:n], p["lr"], getattr(opt, "momentum", 0.0), p["divisor"])
-        if has_state:
-          store.state.copy_(p["state"][:ns], non_blocking=True)
-        if staged:
-          torch.cuda.current_stream(dev).synchronize()     # the landing buffers are free again
-        self.updates_applied += 1
-      else:
-        self.updates_dropped += 1
+      t2 = time.time()
+      busy["recv_wait"] += t2 - t1
+      self._finalize(p, shard, opt, n, ns, has_state, staged, dev)
+      busy["apply"] += time.time() - t2
       free_slots.append(p["slot"])
 
     while active > 0 or inflight:
       if inflight and (active == 0 or not self._request_waiting(k, head)):
         finalize(inflight.popleft())          # nothing else to do: complete the oldest push
         continue
+      t1 = time.time()
       msg = self._next_request(k, head)
+      busy["idle"] += time.time() - t1
       head += 1
       parts = msg.split(":")
       op, src = parts[0], int(parts[1])
@@ -496,6 +556,7 @@ class ParameterServerStrategy(Strategy):
             inflight.remove(p)
             finalize(p)
         dtype = torch.bfloat16 if (len(parts) > 2 and parts[2] == "bf16") else torch.float32
+        t1 = time.time()
         if n:
           out = store.params[a:b]
           if dtype != torch.float32:
@@ -506,13 +567,20 @@ class ParameterServerStrategy(Strategy):
             host = self._buf("serve_host", n, dtype, None, pinned=True)
             host[:n].copy_(out)                # synchronous device-to-host copy
             out = host[:n]
-          self.comm.send(out, src)
+          sends = self._isend(out, src, self.PULL)
+        else:
+          sends = []
+        t2 = time.time()
+        busy["pull_stage"] += t2 - t1
         if has_state:
           st = store.state
           if staged:
             st = self._buf("serve_state", ns, torch.float32, None, pinned=True)
             st[:ns].copy_(store.state)
-          self.comm.send(st[:ns], src)
+          sends += self._isend(st[:ns], src, self.PULL)
+        for w in sends:
+          w.wait()
+        busy["pull_send"] += time.time() - t2
       elif op == "push":
         if not free_slots:
           finalize(inflight.popleft())
@@ -525,13 +593,13 @@ class ParameterServerStrategy(Strategy):
           lo, hi = (int(v) for v in piece.split("-"))
           if not 0 <= lo < hi <= n:
             raise RuntimeError("parameter server: bad piece %s in %r" % (piece, msg))
-          works.append(self.comm.irecv(grads[lo:hi], src))
+          works += self._irecv(grads[lo:hi], src, self.PUSH)
         state = None
         if has_state:
           state = land("ps_state", slot, ns, torch.float32)
-          works.append(self.comm.irecv(state[:ns], src))
+          works += self._irecv(state[:ns], src, self.PUSH)
         trailer = torch.zeros(1, dtype=torch.float32, device="cpu" if staged else dev)
-        works.append(self.comm.irecv(trailer, src))
+        works += self._irecv(trailer, src, self.PUSH)
         p = dict(src=src, slot=slot, lr=lr, divisor=divisor, grads=grads, state=state,
                  trailer=trailer, works=works)
         if self.stream_push:
@@ -544,9 +612,33 @@ class ParameterServerStrategy(Strategy):
         raise RuntimeError("parameter server: bad request %r" % msg)
     if store.device.type == "cuda":
       torch.cuda.synchronize(store.device)
-    logging.info("parameter server %d: %d updates applied, %d dropped in %.1f s; all workers done",
-                 k, self.updates_applied, self.updates_dropped, time.time() - t0)
+    logging.info("parameter server %d: %d updates applied, %d dropped in %.1f s; all workers done "
+                 "(seconds: %s)", k, self.updates_applied, self.updates_dropped, time.time() - t0,
+                 ", ".join("%s %.2f" % kv for kv in busy.items()))
     return self.updates_applied
+
+  def _finalize(self, p, shard, opt, n, ns, has_state, staged, dev):
+    """Applies one completely received push (or drops it when its trailer says so)."""
+    store = shard.store
+    if p["trailer"][0].item() != 0:
+      if n:
+        g = p["grads"]
+        if g.device != dev:
+          tmp = self._buf("ps_dev", n, g.dtype, dev)
+          tmp[:n].copy_(g[:n], non_blocking=True)
+          g = tmp
+        if g.dtype != torch.float32:
+          wide = self._buf("ps_f32", n, torch.float32, dev)
+          wide[:n].copy_(g[:n])
+          g = wide
+        shard.apply_sgd(g[:n], p["lr"], getattr(opt, "momentum", 0.0), p["divisor"])
+      if has_state:
+        store.state.copy_(p["state"][:ns], non_blocking=True)
+      if staged:
+        torch.cuda.current_stream(dev).synchronize()     # the landing buffers are free again
+      self.updates_applied += 1
+    else:
+      self.updates_dropped += 1
 
   def barrier(self):
     pass   # asynchronous by design: no inter-worker barrier

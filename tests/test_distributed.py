@@ -347,7 +347,7 @@ def test_parameter_server_many_workers_no_deadlock_no_lost_update(tmp_path, num_
   body = COMMON + """
 os.environ["DTF_PS_PUSH_DTYPE"] = %r
 strat = S.get_distribution_strategy("parameter_server", num_gpus=0)
-strat.num_packs = 3
+strat.bucket_bytes = 300000
 from distributed_tensorflow_amd.train.optimizers import LossScaleOptimizer
 m = Model(models.resnet20(), strategy=strat, dtype="fp32", seed=11)
 opt = LossScaleOptimizer(SGD(0.01, momentum=0.9), "dynamic", initial_scale=8.0)
