@@ -140,12 +140,41 @@ def _decode(image_buffer: bytes):
   return img if img.mode == "RGB" else img.convert("RGB")     # CMYK / grayscale files exist
 
 
+def _jpeg_draft_enabled() -> bool:
+  return os.environ.get("DTF_JPEG_DRAFT", "1") != "0"
+
+
+def _decode_for_crop(image_buffer: bytes, rng, bbox: np.ndarray, out_h: int, out_w: int):
+  """Training decode: samples the distorted crop box from the header's dimensions first, then
+  lets libjpeg decode at 1/2, 1/4 or 1/8 scale (`Image.draft`: the inverse DCT produces the
+  smaller image directly) when the crop still has at least the output resolution at that scale.
+  An average ImageNet crop (0.08-1.0 of a ~400x350 image, resized to 224x224) rarely qualifies,
+  large photographs always do: their decode time drops by the square of the scale.  Returns the
+  pixels and the crop box in the decoded image's coordinates.  `DTF_JPEG_DRAFT=0` decodes at
+  full size like the reference (`imagenet_preprocessing.py:259-323` crops while decoding but
+  never scales)."""
+  from PIL import Image  # pylint: disable=import-outside-toplevel
+  img = Image.open(io.BytesIO(image_buffer))
+  width, height = img.size
+  y, x, h, w = sample_distorted_bounding_box(height, width, bbox, rng)
+  if _jpeg_draft_enabled() and img.format == "JPEG" and h >= 2 * out_h and w >= 2 * out_w:
+    # the full image at the size where the crop maps onto exactly the output resolution
+    img.draft("RGB", (-(-width * out_w // w), -(-height * out_h // h)))
+    sw, sh = img.size
+    if (sw, sh) != (width, height):
+      fx, fy = sw / width, sh / height
+      x, w = int(x * fx), max(1, int(w * fx))
+      y, h = int(y * fy), max(1, int(h * fy))
+      w, h = min(w, sw - x), min(h, sh - y)
+  if img.mode != "RGB":
+    img = img.convert("RGB")
+  return img, (y, x, h, w)
+
+
 def _decode_crop_and_flip(image_buffer: bytes, bbox: np.ndarray, rng):
   """Random distorted-box crop + random horizontal flip. Returns a PIL image."""
   from PIL import Image  # pylint: disable=import-outside-toplevel
-  img = _decode(image_buffer)
-  width, height = img.size
-  y, x, h, w = sample_distorted_bounding_box(height, width, bbox, rng)
+  img, (y, x, h, w) = _decode_for_crop(image_buffer, rng, bbox, DEFAULT_IMAGE_SIZE, DEFAULT_IMAGE_SIZE)
   img = img.crop((x, y, x + w, y + h))
   if rng.random() < 0.5:
     img = img.transpose(Image.FLIP_LEFT_RIGHT)
@@ -205,13 +234,14 @@ def preprocess_image(image_buffer: bytes, bbox: np.ndarray, output_height: int,
   rng = rng or np.random.default_rng()
   fast = _native_resize() if num_channels == 3 else None
   if fast is not None:
-    pixels = np.asarray(_decode(image_buffer))           # uint8 [H, W, 3]
-    height, width = pixels.shape[0], pixels.shape[1]
     if is_training:
-      y, x, h, w = sample_distorted_bounding_box(height, width, bbox, rng)
+      img, (y, x, h, w) = _decode_for_crop(image_buffer, rng, bbox, output_height, output_width)
+      pixels = np.asarray(img)                             # uint8 [H, W, 3]
       flip = bool(rng.random() < 0.5)
       return fast(pixels, y, x, h, w, output_height, output_width, 0, 0, output_height,
                   output_width, flip, list(_CHANNEL_MEANS))
+    pixels = np.asarray(_decode(image_buffer))           # uint8 [H, W, 3]
+    height, width = pixels.shape[0], pixels.shape[1]
     new_h, new_w = _smallest_size_at_least(height, width, _RESIZE_MIN)
     top, left = (new_h - output_height) // 2, (new_w - output_width) // 2
     return fast(pixels, 0, 0, height, width, new_h, new_w, top, left, output_height,

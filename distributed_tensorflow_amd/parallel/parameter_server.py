@@ -117,7 +117,7 @@ class ParameterServerStrategy(Strategy):
     # gradients travel as bfloat16 when the worker computes in a 16-bit type, unless told otherwise
     self.push_dtype = os.environ.get("DTF_PS_PUSH_DTYPE", "auto").lower()
     # a posted receive is free with gloo and blocks the communicator's stream with RCCL
-    self.stream_push = comm.backend != "nccl"
+    self.stream_push = comm.backend != "nccl" and os.environ.get("DTF_PS_STREAM_PUSH", "1") != "0"
     self._recv_lane = concurrent.futures.ThreadPoolExecutor(1, thread_name_prefix="ps-recv")
     self._send_lane = concurrent.futures.ThreadPoolExecutor(1, thread_name_prefix="ps-send")
     self._prefetched = None        # (future, fmt) of the parameters requested ahead

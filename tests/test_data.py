@@ -335,3 +335,34 @@ def test_evaluate_reports_exhausted_input():
   data = [(torch.zeros(2, 32, 32, 3), torch.zeros(2, 1))] * 2
   with pytest.raises(RuntimeError, match="ran out of data at step 2 of 3"):
     m.evaluate(data, steps=3)
+
+
+def test_training_decode_uses_scaled_jpeg_decoding_for_large_photographs(monkeypatch):
+  """A crop that is at least twice the output resolution is decoded at reduced scale
+  (`Image.draft`, the inverse DCT emits the smaller image): same picture within resampling
+  differences as the full-size decode, and `DTF_JPEG_DRAFT=0` decodes at full size."""
+  import io
+  import numpy as np
+  from PIL import Image
+  from distributed_tensorflow_amd.data import imagenet_preprocessing as ip
+  yy, xx = np.mgrid[0:1200, 0:1600]
+  pix = np.stack([(xx / 8) % 256, (yy / 6) % 256, ((xx + yy) / 12) % 256], -1).astype(np.uint8)
+  buf = io.BytesIO()
+  Image.fromarray(pix).save(buf, format="JPEG", quality=90)
+  raw = buf.getvalue()
+  whole = np.zeros((0, 4), np.float32)        # no boxes: the sampler may pick any crop
+
+  class FullCrop:
+    """Stands in for the random generator: forces the whole image as the crop, no flip."""
+    def random(self):
+      return 0.9
+  monkeypatch.setattr(ip, "sample_distorted_bounding_box", lambda h, w, b, r, **k: (0, 0, h, w))
+  img, box = ip._decode_for_crop(raw, FullCrop(), whole, 224, 224)
+  assert img.size == (400, 300) and box == (0, 0, 300, 400)          # decoded at 1/4 scale
+  a = ip.preprocess_image(raw, whole, 224, 224, 3, True, FullCrop())
+  monkeypatch.setenv("DTF_JPEG_DRAFT", "0")
+  img, box = ip._decode_for_crop(raw, FullCrop(), whole, 224, 224)
+  assert img.size == (1600, 1200) and box == (0, 0, 1200, 1600)
+  b = ip.preprocess_image(raw, whole, 224, 224, 3, True, FullCrop())
+  assert a.shape == b.shape == (224, 224, 3)
+  assert np.abs(a - b).mean() < 6.0            # of 255: same content, different resampling
