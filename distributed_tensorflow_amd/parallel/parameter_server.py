@@ -124,6 +124,7 @@ class ParameterServerStrategy(Strategy):
     self._push: Optional[Dict] = None
     self._last_send = None         # future of the previous step's last transfer
     self._copy_stream = None
+    self._executor = None          # set by orders_side_lane()
     self._h2d_done = None
     # gloo moves one message with one progress thread per process group (2.5 GB/s on the test
     # host, and no faster in both directions at once); transfers are therefore striped over
@@ -233,9 +234,29 @@ class ParameterServerStrategy(Strategy):
     return self._host[key]
 
   def _stream(self, device):
+    """The stream of the staging copies.  HIP multiplexes streams onto a few hardware queues
+    and two streams on one queue run strictly in submission order: a copy stream that shared
+    the queue of the compute stream or of the executor's weight-gradient lane held their
+    kernels up behind its waits and transfers (ResNet-50 step 21.6 -> 29 ms on the GPU).  The
+    native extension hands out a stream it has probed to run concurrently with both."""
     if self._copy_stream is None:
-      self._copy_stream = torch.cuda.Stream(device)
+      from ..ops import native  # pylint: disable=import-outside-toplevel
+      if native.available():
+        main = torch.cuda.default_stream(device)
+        h = native.ext().concurrent_stream(int(main.cuda_stream), 0)
+        self._copy_stream = torch.cuda.ExternalStream(h, device=device)
+      else:
+        self._copy_stream = torch.cuda.Stream(device)
     return self._copy_stream
+
+  def orders_side_lane(self, executor) -> bool:
+    """True when the pushes wait for the executor's side lane (weight gradients) themselves, on
+    the copy stream: the executor may then skip the main-lane joins at bucket boundaries
+    (`HipExecutor.train_step(soft_joins=True)`)."""
+    if not hasattr(executor, "side_stream") or executor.device.type != "cuda":
+      return False
+    self._executor = executor
+    return True
 
   # -- worker side -------------------------------------------------------------------
   def _shards(self, store):
@@ -332,6 +353,7 @@ class ParameterServerStrategy(Strategy):
       self.wait_s["gpu_ms"] += self._step_events[0].elapsed_time(self._step_events[1])
       self._step_events = None
     if store.device.type == "cuda":
+      self._stream(store.device)            # created (and probed) on the training thread
       self._step_events = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
       self._step_events[0].record()
     self._t_begin = time.time()
@@ -365,8 +387,12 @@ class ParameterServerStrategy(Strategy):
     p = self._push
     ev = None
     if p["store"].device.type == "cuda":
-      ev = torch.cuda.Event()
-      ev.record()
+      ev = [torch.cuda.Event()]
+      ev[0].record()
+      side = self._executor.side_stream() if self._executor is not None else None
+      if side is not None:               # the bucket's weight gradients
+        ev.append(torch.cuda.Event())
+        ev[1].record(side)
     p["ready"][bucket.index] = ev
     # buckets leave strictly in the announced order
     while p["next"] < len(p["order"]) and p["order"][p["next"]].index in p["ready"]:
@@ -389,8 +415,8 @@ class ParameterServerStrategy(Strategy):
         torch.cuda.set_device(dev)
         stream = self._stream(dev)
         with torch.cuda.stream(stream):
-          if ev is not None:
-            stream.wait_event(ev)
+          for e in ev or []:
+            stream.wait_event(e)
           if fmt == "bf16":
             half = self._buf("push_half", n, dtype, dev)
             half[bk.start:bk.end].copy_(store.grads[bk.start:bk.end])
@@ -429,8 +455,12 @@ class ParameterServerStrategy(Strategy):
     ev = None
     self.wait_s["host_s"] += time.time() - self._t_begin
     if dev.type == "cuda":
-      ev = torch.cuda.Event()
-      ev.record()
+      side = self._executor.side_stream() if self._executor is not None else None
+      if side is not None:
+        # the executor skipped its joins: the step ends when the weight-gradient lane has
+        torch.cuda.current_stream(dev).wait_stream(side)
+      ev = [torch.cuda.Event()]
+      ev[0].record()
       self._step_events[1].record()
     if not self.stream_push:
       self._post_push()                       # RCCL: announced only now, sent in one go
@@ -448,8 +478,8 @@ class ParameterServerStrategy(Strategy):
       trailer = torch.full((1,), flag, dtype=torch.float32, device="cpu" if staged else dev)
       if dev.type == "cuda":
         torch.cuda.set_device(dev)
-        if ev is not None:
-          ev.synchronize()
+        for e in ev or []:
+          e.synchronize()
         if staged and store.num_state_elements:
           host = self._buf("push_state", store.num_state_elements, torch.float32, None, pinned=True)
           host.copy_(store.state)

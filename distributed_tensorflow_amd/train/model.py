@@ -15,6 +15,7 @@ SGD-momentum(+L2, +loss-scale, +1/replicas) -> metric accumulation on the device
 from __future__ import annotations
 
 import math
+import os
 import sys
 import time
 from typing import Dict, Iterable, List, Optional, Sequence
@@ -153,8 +154,16 @@ class Model:
           logging.warning("data_format channels_first has no effect on the native engine: its "
                           "kernels are written for pixel-major (NHWC) activations; results do "
                           "not depend on the layout")
+        use_graph = self.use_hip_graph
+        if use_graph is None and self.strategy is not None and not self.strategy.synchronous \
+            and "DTF_HIP_GRAPH" not in os.environ:
+          # asynchronous parameter server: the step is interleaved with host-driven transfers
+          # at every bucket boundary, and the first steps (no parameters prefetched yet) are no
+          # basis for the eager / replay calibration: eager launch measured 21.6 ms of GPU time
+          # per ResNet-50 step against 28.4 ms for eight replayed graph segments
+          use_graph = False
         ex = HipExecutor(self.spec, self.store, batch, self.dtype, self._bucket_list(),
-                         use_graph=self.use_hip_graph,
+                         use_graph=use_graph,
                          fused_bn_stats=False if self.deterministic else None)
       else:
         ex = TorchExecutor(self.spec, self.store, batch, self.dtype, self._bucket_list(),
@@ -225,7 +234,9 @@ class Model:
       ex.params_updated()
       scale = self._loss_scale()
       st.begin_push(self.store, self._bucket_list(), self.optimizer.current_lr(), scale, half)
-      loss, correct = ex.train_step(images, idx, scale, st.on_bucket_ready)
+      soft = getattr(ex, "native", False) and st.orders_side_lane(ex)
+      loss, correct = ex.train_step(images, idx, scale, st.on_bucket_ready, soft_joins=soft) \
+          if soft else ex.train_step(images, idx, scale, st.on_bucket_ready)
       finite = True
       ls = self._loss_scale_optimizer()
       if ls is not None and ls.dynamic:

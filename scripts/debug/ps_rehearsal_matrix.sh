@@ -7,6 +7,4 @@ run() {
       --log_steps 20 > gpurun_out/ps_m.log 2>&1 || { tail -5 gpurun_out/ps_m.log; return 1; }
   grep -E "global step':60|waiting|updates|eager" gpurun_out/ps_m.log | cut -c 40-400
 }
-run DTF_HIP_GRAPH=0 DTF_PS_STREAM_PUSH=0 && run DTF_HIP_GRAPH=0 DTF_PS_BUCKET_MB=64 && \
-run DTF_HIP_GRAPH=0 DTF_PS_BUCKET_MB=32 DTF_PS_CHANNELS=2 && run DTF_HIP_GRAPH=0 DTF_WGRAD_STREAM=0 && \
-run DTF_HIP_GRAPH=0 DTF_PS_PUSH_DTYPE=fp32 DTF_PS_BUCKET_MB=200
+run DTF_X=0 && run DTF_HIP_GRAPH=0 && run DTF_HIP_GRAPH=0 DTF_PS_PUSH_DTYPE=fp32 && run DTF_HIP_GRAPH=0 DTF_PS_BUCKET_MB=200
