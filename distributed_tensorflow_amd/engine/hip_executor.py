@@ -868,6 +868,10 @@ class HipExecutor:
         done([op.name + "/gamma", op.name + "/beta"])
       elif op.kind == "conv":
         g = self.geoms[op.name]
+        # The weight gradient is forked before the data gradient is enqueued.  Forking it behind
+        # the data gradient (so that it starts next to the memory-bound BatchNorm sweeps of the
+        # layer below instead of next to a second matrix kernel) measured 21.9 against 21.5 ms:
+        # the sweeps are shorter than a weight gradient, the lane falls behind and ends alone.
         self._add_wgrad(plan, g.wgrad(acts[xname].data_ptr(), dout.data_ptr(),
                                       self._var_ptr(op.name + "/kernel", "grad")),
                         op.name + "/wgrad")
