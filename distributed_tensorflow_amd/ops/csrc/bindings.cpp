@@ -209,8 +209,9 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     // > 0: `ws` already holds that many replica rows of [sum g | sum g*y] left by the data-
     // gradient launches that produced dz; the reduction sweep is skipped
     const int pre = get_or<int>(d, "pre_replicas", 0);
+    auto tail = ptr<float>(d, "tail", false);
     return [=](hipStream_t s) {
-      launch_bn_bwd(dz, y, z, mask, mean, inv, gamma, dgamma, dbeta, dy, dres, ws, P, C, pre, dt, s);
+      launch_bn_bwd(dz, y, z, mask, mean, inv, gamma, dgamma, dbeta, dy, dres, ws, P, C, pre, tail, dt, s);
     };
   }
   if (kind == "bn_bwd_dual") {
@@ -224,9 +225,10 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     auto dg1 = ptr<float>(d, "dgamma"); auto dg2 = ptr<float>(d, "dgamma2");
     auto db1 = ptr<float>(d, "dbeta"); auto db2 = ptr<float>(d, "dbeta2");
     auto dy1 = ptr<void>(d, "dy"); auto dy2 = ptr<void>(d, "dy2");
+    auto tail = ptr<float>(d, "tail", false);
     return [=](hipStream_t s) {
       launch_bn_bwd_dual(dz, mask, P, C, ws, ws2, y1, m1, i1, g1, dg1, db1, dy1, y2, m2, i2, g2, dg2,
-                         db2, dy2, dt, s);
+                         db2, dy2, tail, dt, s);
     };
   }
   if (kind == "mask_apply") {
@@ -609,6 +611,7 @@ PYBIND11_MODULE(_dtf_native, m) {
   m.def("fastdiv_check", [](uint32_t n, uint32_t d) { return fd_div(n, make_fastdiv(d)); });
   m.def("pack_desc_size", []() { return (int)sizeof(PackDesc); });
   m.def("bn_workspace_floats", []() { return bn_workspace_floats(); });
+  m.def("bn_tail_floats", []() { return bn_tail_floats(); });
   m.def("bn_fold_desc_size", []() { return bn_fold_desc_size(); });
   m.attr("PACK_PER_BLOCK") = 256 * 8;
   m.attr("arch") = "gfx950";

@@ -49,7 +49,9 @@ constexpr int MAX_PARTIAL_BLOCKS = 512;   // rows of the partial-sum workspace
 // Per-block partial sums: threads that own the same channel chunk (same tid % tpr) are summed
 // through LDS and the block writes one row [NV/8 quantities][C] of the workspace with plain
 // stores.  No atomics: thousands of blocks adding to the same few addresses serialise in L2.
-template <int NV>
+// ATOMIC: `ws_row` is one of a few replica rows shared by many blocks: the block's sums are
+// added to it (the fused-statistics convolution epilogues accumulate the same way).
+template <int NV, bool ATOMIC = false>
 __device__ __forceinline__ void block_reduce_to_partials(float (&part)[NV], int tpr, int chunk,
                                                          int rowid, float* ws_row, int C) {
   __shared__ float red[TPB * NV];
@@ -88,7 +90,13 @@ __device__ __forceinline__ void block_reduce_to_partials(float (&part)[NV], int 
       }
     }
   }
-  if (rowid == 0) {
+  if (rowid == 0 && ATOMIC) {
+#pragma unroll
+    for (int qn = 0; qn < NV / 8; ++qn) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) atomicAdd(ws_row + qn * C + chunk * 8 + c, part[qn * 8 + c]);
+    }
+  } else if (rowid == 0) {
 #pragma unroll
     for (int qn = 0; qn < NV / 8; ++qn) {
       f32x4 lo = {part[qn * 8 + 0], part[qn * 8 + 1], part[qn * 8 + 2], part[qn * 8 + 3]};
@@ -364,9 +372,15 @@ struct BnBwdArgs {
   // sweep reads dz and the mask once for the two of them.  No ReLU of its own, no dres.
   const void* y2; const float* mean2; const float* invstd2; const float* gamma2;
   float* dgamma2; float* dbeta2; void* dy2; float* ws2;
+  // TAIL instantiations of the reduction: `ws` (`ws2`) are TAIL_REPLICAS zeroed rows of
+  // [dgamma | dbeta] that the blocks add to, `ticket` counts finished blocks; the last one sums
+  // the rows, stores dgamma / dbeta and leaves rows and ticket zeroed for the next launch.
+  unsigned int* ticket;
 };
 
-template <int DT, int NB>
+constexpr int TAIL_REPLICAS = 8;
+
+template <int DT, int NB, bool TAIL = false>
 __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
   const int C = a.C, tpr = C >> 3, rpb = TPB / tpr;
   const int chunk = threadIdx.x % tpr, rowid = threadIdx.x / tpr;
@@ -435,15 +449,51 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
     const Raw8<DT> y2q = NB == 2 ? ldraw<DT>(a.y2, off) : zero_raw<DT>();
     accumulate(gv, yq, zq, bits, y2q);
   }
+  const size_t wrow = (size_t)(TAIL ? blockIdx.x % TAIL_REPLICAS : blockIdx.x) * 2 * C;
   if constexpr (NB == 2) {
     float second[16];                // [dgamma2 | dbeta] (same g: same dbeta), copied before the
 #pragma unroll                       // first reduction overwrites `part` in the writing threads
     for (int c = 0; c < 8; ++c) { second[c] = part2[c]; second[8 + c] = part[8 + c]; }
-    block_reduce_to_partials<16>(part, tpr, chunk, rowid, a.ws + (size_t)blockIdx.x * 2 * C, C);
+    block_reduce_to_partials<16, TAIL>(part, tpr, chunk, rowid, a.ws + wrow, C);
     __syncthreads();                 // the LDS scratch of the reduction is reused
-    block_reduce_to_partials<16>(second, tpr, chunk, rowid, a.ws2 + (size_t)blockIdx.x * 2 * C, C);
+    block_reduce_to_partials<16, TAIL>(second, tpr, chunk, rowid, a.ws2 + wrow, C);
   } else {
-    block_reduce_to_partials<16>(part, tpr, chunk, rowid, a.ws + (size_t)blockIdx.x * 2 * C, C);
+    block_reduce_to_partials<16, TAIL>(part, tpr, chunk, rowid, a.ws + wrow, C);
+  }
+  if constexpr (TAIL) {
+    // The block that takes the last ticket finds every other block's sums in the replica rows:
+    // each block fences its atomics before it draws, the last one fences before it reads.
+    __shared__ unsigned int is_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (is_last == 0u) return;
+    __threadfence();
+    for (int ch = threadIdx.x; ch < C; ch += TPB) {
+      float dg = 0.f, db = 0.f, dg2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < TAIL_REPLICAS; ++r) {
+        float* row = a.ws + (size_t)r * 2 * C;
+        dg += __hip_atomic_load(row + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        db += __hip_atomic_load(row + C + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        row[ch] = 0.f;
+        row[C + ch] = 0.f;
+        if constexpr (NB == 2) {
+          float* row2 = a.ws2 + (size_t)r * 2 * C;
+          dg2 += __hip_atomic_load(row2 + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          row2[ch] = 0.f;
+          row2[C + ch] = 0.f;
+        }
+      }
+      a.dgamma[ch] = dg;     // plain stores into the flat gradient buffer
+      a.dbeta[ch] = db;
+      if constexpr (NB == 2) {
+        a.dgamma2[ch] = dg2;
+        a.dbeta2[ch] = db;
+      }
+    }
+    if (threadIdx.x == 0) *a.ticket = 0u;
   }
 }
 
@@ -904,7 +954,8 @@ void launch_bn_pool_bwd(const void* dzp, const uint8_t* idx, const void* y, cons
     DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_pool_bwd_kernel<DT, false, 0>), dim3(G), dim3(TPB), 0, s, a));
   }
   BnBwdArgs b{nullptr, y, nullptr, nullptr, mean, invstd, gamma, dgamma, dbeta, dy, nullptr, ws, G,
-              N * H * W, C, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+              N * H * W, C, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+              nullptr};
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, b);
   const int ga = rows < 8192 ? rows : 8192;
   if (stride == 2) {
@@ -936,22 +987,35 @@ void launch_bn_infer(const void* y, const void* res, void* z, const float* gamma
                                        dim3(TPB), 0, s, a));
 }
 
+size_t bn_tail_floats() { return 16 + 2 * (size_t)TAIL_REPLICAS * 2 * 2048; }
+
 void launch_bn_bwd(const void* dz, const void* y, const void* z, const uint8_t* mask,
                    const float* mean, const float* invstd, const float* gamma, float* dgamma,
                    float* dbeta, void* dy, void* dres, float* ws, int P, int C,
-                   int pre_replicas, int dt, hipStream_t s) {
+                   int pre_replicas, float* tail, int dt, hipStream_t s) {
   check_channels(C, P);
   if (pre_replicas < 0) throw std::invalid_argument("bn_bwd: negative replica count");
   const int G = pre_replicas > 0 ? pre_replicas : reduce_grid(P, C);
   BnBwdArgs a{dz, y, z, mask, mean, invstd, gamma, dgamma, dbeta, dy, dres, ws, G, P, C,
               pre_replicas > 0 ? 1 : 0,
-              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   static const bool fold_ok = [] {
     const char* e = std::getenv("DTF_BN_FOLD_FINALIZE");
     return !(e && e[0] == '0');
   }();
   if (fold_ok && pre_replicas > 0 && pre_replicas * 2 * C <= 16384 && C <= FOLD_MAX_C) {
     DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, true>), dim3(rows_grid(P, C)),
+                                         dim3(TPB), 0, s, a));
+    return;
+  }
+  if (pre_replicas == 0 && tail != nullptr) {
+    // the reduction's last block finalises: no separate launch between the two sweeps
+    BnBwdArgs t = a;
+    t.ticket = reinterpret_cast<unsigned int*>(tail);
+    t.ws = tail + 16;
+    DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_reduce_kernel<DT, 1, true>), dim3(G), dim3(TPB), 0,
+                                         s, t));
+    DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, false>), dim3(rows_grid(P, C)),
                                          dim3(TPB), 0, s, a));
     return;
   }
@@ -971,12 +1035,23 @@ void launch_bn_bwd_dual(const void* dz, const uint8_t* mask, int P, int C, float
                         const float* gamma1, float* dgamma1, float* dbeta1, void* dy1,
                         const void* y2, const float* mean2, const float* invstd2,
                         const float* gamma2, float* dgamma2, float* dbeta2, void* dy2,
-                        int dt, hipStream_t s) {
+                        float* tail, int dt, hipStream_t s) {
   check_channels(C, P);
   if (ws == ws2) throw std::invalid_argument("bn_bwd_dual: the two layers need separate workspaces");
   const int G = reduce_grid(P, C);
   BnBwdArgs a{dz, y1, nullptr, mask, mean1, invstd1, gamma1, dgamma1, dbeta1, dy1, nullptr, ws, G,
-              P, C, 0, y2, mean2, invstd2, gamma2, dgamma2, dbeta2, dy2, ws2};
+              P, C, 0, y2, mean2, invstd2, gamma2, dgamma2, dbeta2, dy2, ws2, nullptr};
+  if (tail != nullptr) {
+    BnBwdArgs t = a;
+    t.ticket = reinterpret_cast<unsigned int*>(tail);
+    t.ws = tail + 16;
+    t.ws2 = tail + 16 + (size_t)TAIL_REPLICAS * 2 * 2048;
+    DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_reduce_kernel<DT, 2, true>), dim3(G), dim3(TPB), 0,
+                                         s, t));
+    DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, false, 2>), dim3(rows_grid(P, C)),
+                                         dim3(TPB), 0, s, a));
+    return;
+  }
   DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_reduce_kernel<DT, 2>), dim3(G), dim3(TPB), 0, s, a));
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, a);
   BnBwdArgs b = a;                   // the finalize kernel reads the first layer's fields

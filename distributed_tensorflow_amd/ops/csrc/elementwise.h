@@ -33,14 +33,19 @@ void launch_bn_bwd_dual(const void* dz, const uint8_t* mask, int P, int C, float
                         const float* gamma1, float* dgamma1, float* dbeta1, void* dy1,
                         const void* y2, const float* mean2, const float* invstd2,
                         const float* gamma2, float* dgamma2, float* dbeta2, void* dy2,
-                        int dt, hipStream_t s);
+                        float* tail, int dt, hipStream_t s);
 void launch_bn_infer(const void* y, const void* res, void* z, const float* gamma,
                      const float* beta, const float* mm, const float* mv, int P, int C, float eps,
                      int relu, int dt, hipStream_t s);
 void launch_bn_bwd(const void* dz, const void* y, const void* z, const uint8_t* mask,
                    const float* mean, const float* invstd, const float* gamma, float* dgamma,
                    float* dbeta, void* dy, void* dres, float* ws, int P, int C,
-                   int pre_replicas, int dt, hipStream_t s);
+                   int pre_replicas, float* tail, int dt, hipStream_t s);
+// `tail` (optional, bn_tail_floats() zeroed floats, shared by launches of one stream): the
+// reduction sweep adds its per-block sums to a few replica rows and its last block derives
+// dgamma / dbeta, so no finalize launch sits between the two sweeps.  The sums then depend on
+// the order of the atomic additions; without `tail` they are deterministic.
+size_t bn_tail_floats();
 
 // out[i] = bit (i % 8) of mask[i / 8] ? x[i] : 0, n a multiple of 8 (materialises a masked
 // gradient when its consumer cannot apply the mask itself).

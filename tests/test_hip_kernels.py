@@ -750,3 +750,62 @@ def test_fused_sgd_matches_keras_rule():
   v_ref = 0.9 * v0 - 0.1 * gg
   assert torch.allclose(v, v_ref, rtol=1e-6, atol=1e-7)
   assert torch.allclose(p, p0 + v_ref, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("P,C,dual", [(50176, 256, False), (12544, 2048, False), (3000, 64, False),
+                                      (12544, 1024, True), (777, 8, False)])
+def test_batchnorm_backward_reduction_finalised_by_its_last_block(P, C, dual):
+  """`tail`: the reduction sweep adds block sums to replica rows and its last block derives
+  dgamma / dbeta (no finalize launch).  Same results as the deterministic three-launch path
+  within summation-order differences, for the single and the dual (shared gradient) form; the
+  replica rows and the ticket are left zeroed, so the second call sees a clean slate."""
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator().manual_seed(P + C)
+  ext = native.ext()
+  tail = torch.zeros(ext.bn_tail_floats(), device=dev)
+  ws = torch.empty(ext.bn_workspace_floats(), device=dev)
+  ws2 = torch.empty(ext.bn_workspace_floats(), device=dev)
+
+  def layer():
+    y = _bf(torch.randn(P, C, generator=gen) * 2 + 0.5).to(dev)
+    mean = y.float().mean(0)
+    invstd = torch.rsqrt(y.float().var(0, unbiased=False) + 1e-5)
+    gamma = (torch.rand(C, generator=gen) + 0.5).to(dev)
+    return y, mean.contiguous(), invstd.contiguous(), gamma
+
+  dz = _bf(torch.randn(P, C, generator=gen)).to(dev)
+  mask = torch.randint(0, 256, (P * C // 8 + 4,), generator=gen, dtype=torch.uint8).to(dev)
+  L1, L2 = layer(), layer()
+  outs = {}
+  for mode in ("plain", "tail", "tail_again"):
+    t = None if mode == "plain" else tail.data_ptr()
+    r = [torch.zeros(C, device=dev) for _ in range(4)]
+    dy1 = torch.empty(P, C, dtype=torch.bfloat16, device=dev)
+    dy2 = torch.empty(P, C, dtype=torch.bfloat16, device=dev)
+    if dual:
+      native.run_op("bn_bwd_dual", dict(
+          dz=dz.data_ptr(), mask=mask.data_ptr(), P=P, C=C, ws=ws.data_ptr(), ws2=ws2.data_ptr(),
+          y=L1[0].data_ptr(), mean=L1[1].data_ptr(), invstd=L1[2].data_ptr(), gamma=L1[3].data_ptr(),
+          dgamma=r[0].data_ptr(), dbeta=r[1].data_ptr(), dy=dy1.data_ptr(),
+          y2=L2[0].data_ptr(), mean2=L2[1].data_ptr(), invstd2=L2[2].data_ptr(), gamma2=L2[3].data_ptr(),
+          dgamma2=r[2].data_ptr(), dbeta2=r[3].data_ptr(), dy2=dy2.data_ptr(), tail=t))
+    else:
+      native.run_op("bn_bwd", dict(
+          dz=dz.data_ptr(), y=L1[0].data_ptr(), z=None, mask=mask.data_ptr(), mean=L1[1].data_ptr(),
+          invstd=L1[2].data_ptr(), gamma=L1[3].data_ptr(), dgamma=r[0].data_ptr(), dbeta=r[1].data_ptr(),
+          dy=dy1.data_ptr(), dres=None, ws=ws.data_ptr(), P=P, C=C, tail=t))
+    torch.cuda.synchronize()
+    outs[mode] = (r, dy1.float(), dy2.float())
+    assert tail.abs().sum().item() == 0.0            # rows and ticket are clean again
+  # fp32 reference of the sums
+  bits = ((mask[:P * C // 8].view(P, C // 8, 1).to(torch.int32) >> torch.arange(8, device=dev)) & 1)
+  g = dz.float() * bits.view(P, C).float()
+  xhat = (L1[0].float() - L1[1]) * L1[2]
+  assert torch.allclose(outs["plain"][0][0], (g * xhat).sum(0), rtol=1e-3, atol=1e-2)
+  for mode in ("tail", "tail_again"):
+    for a, b in zip(outs[mode][0], outs["plain"][0]):
+      assert torch.allclose(a, b, rtol=1e-4, atol=1e-2 * max(1.0, (P / 1e4) ** 0.5)), mode
+    assert torch.allclose(outs[mode][1], outs["plain"][1], rtol=2e-2, atol=2e-2)
+    if dual:
+      assert torch.allclose(outs[mode][2], outs["plain"][2], rtol=2e-2, atol=2e-2)
