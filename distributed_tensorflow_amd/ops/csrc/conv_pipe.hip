@@ -323,7 +323,7 @@ bool launch_pipe(const ConvParams& p, hipStream_t stream) {
 // Two-stage tile of conv_igemm.hip with the footprint of pipeline configuration `cfg`.
 int pipe_fallback_cfg(int cfg) {
   switch (cfg) {
-    case 16: case 17: case 26: return 6;
+    case 16: case 17: case 26: case 28: case 29: case 30: case 31: return 6;
     case 18: case 19: case 20: case 27: case 25: return 0;
     case 21: return 5;
     case 22: case 23: return 1;
@@ -349,6 +349,12 @@ bool launch_conv_pipe(const ConvParams& p, int cfg, hipStream_t stream) {
     case 25: return launch_pipe<128, 256, 2, 4, 64, 3>(p, stream);   // 144 KiB, 1 block / CU
     case 26: return launch_pipe<256, 128, 4, 2, 32, 4>(p, stream);   //  96 KiB, 1 block / CU
     case 27: return launch_pipe<128, 128, 2, 2, 32, 4>(p, stream);   //  64 KiB, 2 blocks / CU
+    // 128 x 64 per wave (12 fragment reads per 32 MFMAs instead of 8 per 16) and 256-wide blocks
+    // (a third fewer bytes staged per multiply-add)
+    case 28: return launch_pipe<256, 128, 2, 2, 32, 3>(p, stream);   //  72 KiB, 2 blocks / CU, 4 waves
+    case 29: return launch_pipe<256, 256, 2, 4, 32, 3>(p, stream);   //  96 KiB, 1 block / CU, 8 waves
+    case 30: return launch_pipe<256, 256, 4, 4, 32, 3>(p, stream);   //  96 KiB, 1 block / CU, 16 waves
+    case 31: return launch_pipe<128, 256, 2, 4, 32, 3>(p, stream);   //  72 KiB, 2 blocks / CU
     default: throw std::invalid_argument("conv_pipe: unknown tile config");
   }
 }

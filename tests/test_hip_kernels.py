@@ -101,7 +101,7 @@ def test_conv_fwd_dgrad_wgrad(case):
   assert err <= 0.01 * wr.grad.abs().max().item() + 1e-2, err
 
 
-PIPE_CFGS = list(range(16, 28))
+PIPE_CFGS = list(range(16, 32))
 
 
 @pytest.mark.parametrize("cfg", PIPE_CFGS)
