@@ -87,17 +87,17 @@ def main():
     sweep_txt = ""
     if "sweep" in overrides:
       rows = []
-      for c in overrides["sweep"]:
-        fd2 = dict(fd, cfg=c)
+      for sc in overrides["sweep"]:
+        fd2 = dict(fd, cfg=sc)
         tf = timeit(lambda: native.run_op("conv", fd2), iters=10, warm=2)
         td = 0.0
         if not is_first:
-          dd2 = [dict(d, cfg=c) for d in dds]
+          dd2 = [dict(d, cfg=sc) for d in dds]
           td = timeit(lambda: [native.run_op("conv", d) for d in dd2], iters=10, warm=2)
-        rows.append((c, tf, td))
+        rows.append((sc, tf, td))
       bf = min(rows, key=lambda r: r[1]); bd = min(rows, key=lambda r: r[2])
-      sweep_txt = "    sweep fwd: " + " ".join("%d:%.1f%s" % (c, tf, "*" if c == bf[0] else "") for c, tf, _ in rows)
-      sweep_txt += "\n    sweep dgrad: " + " ".join("%d:%.1f%s" % (c, td, "*" if c == bd[0] else "") for c, _, td in rows)
+      sweep_txt = "    sweep fwd: " + " ".join("%d:%.1f%s" % (sc, tf, "*" if sc == bf[0] else "") for sc, tf, _ in rows)
+      sweep_txt += "\n    sweep dgrad: " + " ".join("%d:%.1f%s" % (sc, td, "*" if sc == bd[0] else "") for sc, _, td in rows)
       tot["fwd_best"] += n * min(bf[1], t_f); tot["dgrad_best"] += n * (min(bd[2], t_d) if t_d else 0)
     rf = max(2 * macs / PEAK_TF / 1e6, bytes_f / PEAK_GBS / 1e3)
     print("%-34s %3d %9.2f | %8.1f %7.1f %6.0f | %8.1f %7.1f | %8.1f %7.1f %4d | %6.1f" % (
@@ -106,16 +106,16 @@ def main():
         t_w, 2 * macs / t_w / 1e6, wgd["splits"], rf))
     if "sweep_w" in overrides:
       rows = []
-      for c in overrides["sweep_w"]:
+      for wc in overrides["sweep_w"]:
         for sp in sorted({wgd["splits"], max(1, wgd["splits"] // 2), wgd["splits"] * 2}):
-          w2 = dict(wgd, cfg=c, splits=sp)
+          w2 = dict(wgd, cfg=wc, splits=sp)
           try:
-            rows.append((c, sp, timeit(lambda: native.run_op("wgrad", w2), iters=10, warm=2)))
+            rows.append((wc, sp, timeit(lambda: native.run_op("wgrad", w2), iters=10, warm=2)))
           except Exception:
             pass
       bw = min(rows, key=lambda r: r[2])
       sweep_txt += ("\n" if sweep_txt else "") + "    sweep wgrad (cfg/splits:us): " + " ".join(
-          "%d/%d:%.1f%s" % (c, sp, t, "*" if (c, sp) == bw[:2] else "") for c, sp, t in rows)
+          "%d/%d:%.1f%s" % (wc, sp, t, "*" if (wc, sp) == bw[:2] else "") for wc, sp, t in rows)
       tot["wgrad_best"] += n * min(bw[2], t_w)
     if sweep_txt: print(sweep_txt, flush=True)
     tot["fwd"] += n * t_f; tot["dgrad"] += n * t_d; tot["wgrad"] += n * t_w
