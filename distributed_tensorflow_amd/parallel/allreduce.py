@@ -81,7 +81,13 @@ class GradientReducer:
     internal stream, `async_op=True`)."""
     if self._stream is None:
       self._stream = False
-      if (self.comm.backend == "nccl" and device.type == "cuda"
+      # Small-message policy: a model whose whole gradient is one bucket (ResNet-56: 3.4 MB) has
+      # nothing left to overlap when the bucket completes - the collective is issued from the
+      # compute stream's own position (torch.distributed's stream waits for it and the optimizer
+      # waits for the collective), which saves the two extra cross-stream hops of a private
+      # communication stream.  DTF_COMM_STREAM=own forces the private stream.
+      single = len(self.buckets) <= 1 and os.environ.get("DTF_COMM_STREAM") != "own"
+      if (self.comm.backend == "nccl" and device.type == "cuda" and not single
           and os.environ.get("DTF_COMM_STREAM", "own") != "torch"):
         from ..ops import native  # pylint: disable=import-outside-toplevel
         if native.available():
