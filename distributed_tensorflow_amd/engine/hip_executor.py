@@ -144,6 +144,7 @@ class HipExecutor:
     self.fused_bn_stats = fused_bn_stats and self.dt == 0
     self.overlap_wgrad = os.environ.get("DTF_WGRAD_STREAM", "1") != "0"
     self.wgrad_group = int(os.environ.get("DTF_WGRAD_GROUP", "0"))   # 0: decided while planning
+    self.wgrad_batch = os.environ.get("DTF_WGRAD_BATCH", "1") != "0"
     self._wgrad_queue: List[Tuple[Dict, str]] = []
     self._keep: List[torch.Tensor] = []      # owns every planned buffer
     self._soft_joins = False
@@ -488,8 +489,29 @@ class HipExecutor:
     if not self._wgrad_queue:
       return
     plan.add("fork", {}, self._wgrad_queue[0][1] + "/fork")
+    # Layers of identical geometry (the eighteen convolutions of a CIFAR ResNet stage) differ
+    # only in their three tensors: a run of them becomes one launch with a grid z-slice per
+    # layer, which takes a device table of (x, dy, dw) pointers.
+    runs: List[List[Tuple[Dict, str]]] = []
     for desc, name in self._wgrad_queue:
-      self._add(plan, "wgrad", desc, name, lane=1)
+      key = {k: v for k, v in desc.items() if k not in ("x", "dy", "dw")}
+      if self.wgrad_batch and runs and runs[-1][0][2] == key:
+        runs[-1].append((desc, name, key))
+      else:
+        runs.append([(desc, name, key)])
+    for run in runs:
+      if len(run) == 1:
+        self._add(plan, "wgrad", run[0][0], run[0][1], lane=1)
+        continue
+      table = torch.tensor([[d["x"], d["dy"], d["dw"]] for d, _n, _k in run], dtype=torch.int64,
+                           device=self.device)
+      self._keep.append(table)
+      desc = dict(run[0][2], batch=table.data_ptr(), nbatch=len(run), x=run[0][0]["x"],
+                  dy=run[0][0]["dy"], dw=run[0][0]["dw"])
+      # tile configuration as measured for one layer of this geometry
+      tuned = autotune.apply("wgrad", run[0][0])
+      desc.update(cfg=tuned.get("cfg", 0), splits=tuned.get("splits", desc.get("splits", 1)))
+      plan.add("wgrad", desc, "+".join(n for _d, n, _k in run), 1)
     self._wgrad_queue = []
 
   def _wf_ptr(self, name):

@@ -89,9 +89,12 @@ ConvParams conv_from_dict(const py::dict& d) {
 WgradParams wgrad_from_dict(const py::dict& d) {
   WgradParams p;
   p.dt = get_or<int>(d, "dt", DT_BF16);
-  p.x = ptr<const void>(d, "x");
-  p.dy = ptr<const void>(d, "dy");
-  p.dw = ptr<float>(d, "dw");
+  // "batch": device array of (x, dy, dw) pointer triples, "nbatch" layers of this geometry
+  p.batch = reinterpret_cast<const WgradBatchItem*>(ptr<const void>(d, "batch", false));
+  p.nbatch = get_or<int>(d, "nbatch", 1);
+  p.x = ptr<const void>(d, "x", p.batch == nullptr);
+  p.dy = ptr<const void>(d, "dy", p.batch == nullptr);
+  p.dw = ptr<float>(d, "dw", p.batch == nullptr);
   p.N = get<int>(d, "N"); p.H = get<int>(d, "H"); p.W = get<int>(d, "W");
   p.Cpix = get<int>(d, "Cpix");
   p.OH = get<int>(d, "OH"); p.OW = get<int>(d, "OW");

@@ -99,8 +99,15 @@ using conv_epi::EPI_INFER;
 // e of the lane's chunk to step e (K index 4 * (lane / 16) + e for both operands, so the sum
 // over a row's 16 elements is complete).  fp32 in, fp32 accumulate: exact fp32 products at
 // 1/16 of the 16-bit rate.
-template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int EPI = EPI_PLAIN>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 4)
+//
+// STAGES > 2: the two buffers become a ring and up to STAGES - 1 K-steps are in flight (counted
+// vmcnt waits, one raw barrier per step, as in conv_pipe.hip) for *any* gather.  This is for
+// the short reductions of the CIFAR ResNets (K = 144 .. 576 in 32-wide steps whose channels
+// straddle taps): with two buffers such a block is a chain of 5 - 18 dependent DMA round trips
+// and nothing else, with a ring it is two or three.
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int EPI = EPI_PLAIN,
+          int STAGES = 2>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 4 : 2)
 void conv_igemm_kernel(const ConvParams p) {
   typedef typename Elem<DT>::T T;
   constexpr int EPC = 16 / (int)sizeof(T);          // elements per 16-byte chunk: 8 or 4
@@ -116,7 +123,8 @@ void conv_igemm_kernel(const ConvParams p) {
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
   static_assert(BM % RPP == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
 
-  __shared__ __attribute__((aligned(16))) uint8_t smem[2 * (XBYTES + WBYTES)];
+  static_assert(STAGES >= 2 && STAGES <= 6, "ring depth");
+  __shared__ __attribute__((aligned(16))) uint8_t smem[STAGES * (XBYTES + WBYTES)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -291,6 +299,65 @@ void conv_igemm_kernel(const ConvParams p) {
     for (int mr = 0; mr < MR; ++mr) acc[nr][mr] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int KT = (p.Ktotal + BK - 1) / BK;
+  if constexpr (STAGES > 2) {
+    // ---- ring of STAGES buffers ----------------------------------------------------------
+    // vector-memory operations this wave issues per stage: its pixel pieces plus the weight
+    // pieces that fall to it (wave-uniform: WV, or WV - 1 when the tile has fewer pieces)
+    const bool w_all = RPP * (WV - 1) + wave * 16 < BN;
+    auto issue = [&](int buf) {
+      if constexpr (MODE == TAPLOOP) {
+        issue_tile_tap(buf);
+      } else {
+        issue_tile(buf);
+        advance_k();
+      }
+    };
+    auto wait_landed = [&](int ahead) {            // `ahead` later stages may stay in flight
+      if (ahead <= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+      if (w_all) {
+        if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * (XV + WV)) : "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (XV + WV)) : "memory");
+        else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (XV + WV)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (XV + WV)) : "memory");
+      } else {
+        if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * (XV + WV - 1)) : "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (XV + WV - 1)) : "memory");
+        else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (XV + WV - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (XV + WV - 1)) : "memory");
+      }
+    };
+    static_assert(4 * (XV + WV) < 64, "vmcnt range");
+    if constexpr (MODE == TAPLOOP) setup_tap();
+    {
+      const int pre = KT < STAGES - 1 ? KT : STAGES - 1;
+      for (int sgi = 0; sgi < pre; ++sgi) issue(sgi);
+    }
+    int rbuf = 0, ibuf = STAGES - 1;
+    for (int kt = 0; kt < KT; ++kt) {
+      const int left = KT - 1 - kt;
+      wait_landed(left < STAGES - 2 ? left : STAGES - 2);
+      // own LDS reads of the previous step retired, then the block meets: step kt has landed
+      // for every wave and nobody still reads the buffer that is refilled next
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (kt + STAGES - 1 < KT) {
+        issue(ibuf);
+        if (++ibuf == STAGES) ibuf = 0;
+      }
+      const uint8_t* xs = smem + rbuf * (XBYTES + WBYTES);
+      const uint8_t* ws = xs + XBYTES;
+      if (++rbuf == STAGES) rbuf = 0;
+      u32x4 wf[NR], xf[MR];
+#pragma unroll
+      for (int nr = 0; nr < NR; ++nr) wf[nr] = *reinterpret_cast<const u32x4*>(ws + woff[nr]);
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr) xf[mr] = *reinterpret_cast<const u32x4*>(xs + xoff[mr]);
+#pragma unroll
+      for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+          acc[nr][mr] = mfma_step<DT>(wf[nr], xf[mr], acc[nr][mr]);
+    }
+  } else {
   if constexpr (MODE == TAPLOOP) {
     setup_tap();
     if (KT > 0) issue_tile_tap(0);
@@ -327,6 +394,7 @@ void conv_igemm_kernel(const ConvParams p) {
     dma_wait_all();
     __syncthreads();
   }
+  }
 
   if constexpr (DT == DT_BF16)
     conv_epi::conv_epilogue<MR, NR, POINTWISE, EPI>(p, acc, m0 + wm * WM,
@@ -336,7 +404,7 @@ void conv_igemm_kernel(const ConvParams p) {
                                                          n0 + wn * WN + fq * 4 * NR, lane);
 }
 
-template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int STAGES = 2>
 void launch_cfg_epi(const ConvParams& p, hipStream_t stream) {
   const int tilesN = (p.Cout + BN - 1) / BN;
   const int tilesM = (p.M + BM - 1) / BM;
@@ -346,14 +414,14 @@ void launch_cfg_epi(const ConvParams& p, hipStream_t stream) {
                          p.OH == p.H && p.OW == p.W && p.OHfull == p.OH && p.OWfull == p.OW &&
                          p.Ctap <= p.Cpix;
   if (pointwise)
-    hipLaunchKernelGGL((conv_igemm_kernel<DT, BM, BN, WAVES_M, WAVES_N, POINTWISE_MODE, EPI>),
+    hipLaunchKernelGGL((conv_igemm_kernel<DT, BM, BN, WAVES_M, WAVES_N, POINTWISE_MODE, EPI, STAGES>),
                        dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
   else if (p.Ctap % bk_of(DT) == 0)
-    hipLaunchKernelGGL((conv_igemm_kernel<DT, BM, BN, WAVES_M, WAVES_N, TAPLOOP, EPI>), dim3(grid),
-                       dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<DT, BM, BN, WAVES_M, WAVES_N, TAPLOOP, EPI, STAGES>),
+                       dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<DT, BM, BN, WAVES_M, WAVES_N, GENERIC, EPI>), dim3(grid),
-                       dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<DT, BM, BN, WAVES_M, WAVES_N, GENERIC, EPI, STAGES>),
+                       dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
 }
 
 // The fused epilogues (BatchNorm statistics, folded inference BatchNorm) exist for bfloat16, the
@@ -366,6 +434,15 @@ void launch_cfg(const ConvParams& p, hipStream_t stream) {
   if (p.scale) launch_cfg_epi<DT_BF16, BM, BN, WAVES_M, WAVES_N, EPI_INFER>(p, stream);
   else if (p.stats_y) launch_cfg_epi<DT_BF16, BM, BN, WAVES_M, WAVES_N, EPI_BSTATS>(p, stream);
   else launch_cfg_epi<DT_BF16, BM, BN, WAVES_M, WAVES_N, EPI_PLAIN>(p, stream);
+}
+
+// Ring variants (cfg 8..13): bfloat16 training kernels; other element types and the inference
+// epilogue take the two-stage kernel of the same tile.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+void launch_ring(const ConvParams& p, hipStream_t stream) {
+  if (p.dt != DT_BF16 || p.scale) return launch_cfg<BM, BN, WAVES_M, WAVES_N>(p, stream);
+  if (p.stats_y) launch_cfg_epi<DT_BF16, BM, BN, WAVES_M, WAVES_N, EPI_BSTATS, STAGES>(p, stream);
+  else launch_cfg_epi<DT_BF16, BM, BN, WAVES_M, WAVES_N, EPI_PLAIN, STAGES>(p, stream);
 }
 
 }  // namespace
@@ -438,6 +515,13 @@ void launch_conv_igemm(const ConvParams& p, int cfg, hipStream_t stream) {
     case 4: launch_cfg<64, 128, 1, 4>(p, stream); break;
     case 5: launch_cfg<128, 64, 2, 2>(p, stream); break;
     case 6: launch_cfg<256, 128, 4, 2>(p, stream); break;   // 8 waves: 1.5x the FLOP per L2 byte
+    //                       BM   BN  WM WN  ring          LDS, blocks / CU
+    case 8: launch_ring<256, 16, 4, 1, 4>(p, stream); break;    // 68 KiB, 2
+    case 9: launch_ring<256, 32, 4, 1, 4>(p, stream); break;    // 72 KiB, 2
+    case 10: launch_ring<128, 64, 2, 2, 4>(p, stream); break;   // 48 KiB, 3
+    case 11: launch_ring<256, 64, 4, 1, 4>(p, stream); break;   // 80 KiB, 2
+    case 12: launch_ring<128, 16, 4, 1, 6>(p, stream); break;   // 54 KiB, 2
+    case 13: launch_ring<128, 32, 4, 1, 6>(p, stream); break;   // 60 KiB, 2
     default: throw std::invalid_argument("conv_igemm: unknown tile config");
   }
 }

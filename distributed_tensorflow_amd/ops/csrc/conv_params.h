@@ -44,8 +44,17 @@ struct ConvParams {
 
 // Weight gradient: dW[k][co] += sum over pixels of X[pixel, k] * dY[pixel, co], where
 // k = (tap i, tap j, channel c) gathers X exactly like the forward pass.
+// One layer of a batched weight-gradient launch: layers of identical geometry (a stage of a
+// CIFAR ResNet has eighteen) differ only in their three tensors.
+struct WgradBatchItem {
+  const void* x; const void* dy; float* dw;
+};
+
 struct WgradParams {
   int dt = DT_BF16;                // element type of x / dy
+  // batched launch: device array of `nbatch` items, one grid z-slice each (x / dy / dw unused)
+  const WgradBatchItem* batch = nullptr;
+  int nbatch = 1;
   const void* x = nullptr;         // forward input [N, H, W, Cpix]
   const void* dy = nullptr;        // output gradient [N, OH, OW, ldy]
   float* dw = nullptr;             // fp32 [TIr*TJr*Creal][Cout] (Keras HWIO), accumulated atomically

@@ -172,8 +172,15 @@ void conv_wgrad_kernel(const WgradParams p) {
   const int ycol = c0 + ych * EPC;
   const bool yc_ok = ycol < p.Cout;
 
-  const T* __restrict__ gx = reinterpret_cast<const T*>(p.x);
-  const T* __restrict__ gy = reinterpret_cast<const T*>(p.dy);
+  const void* px = p.x;
+  const void* pdy = p.dy;
+  float* pdw = p.dw;
+  if (p.batch != nullptr) {          // block-uniform: the layer this z-slice works on
+    const WgradBatchItem it = p.batch[blockIdx.z];
+    px = it.x; pdy = it.dy; pdw = it.dw;
+  }
+  const T* __restrict__ gx = reinterpret_cast<const T*>(px);
+  const T* __restrict__ gy = reinterpret_cast<const T*>(pdy);
   const T* zero_page = reinterpret_cast<const T*>(g_zero_page_w);
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -353,7 +360,7 @@ void conv_wgrad_kernel(const WgradParams p) {
       const uint32_t tir = fd_div(t, p.divTJpad);
       const int tjr = (int)t - (int)tir * p.TJpad;
       if (c >= p.Creal || tjr >= p.TJreal) continue;
-      float* row = p.dw + (size_t)(((int)tir * p.TJreal + tjr) * p.Creal + c) * p.Cout;
+      float* row = pdw + (size_t)(((int)tir * p.TJreal + tjr) * p.Creal + c) * p.Cout;
 #pragma unroll
       for (int b = 0; b < CR; ++b) {
         const int co = c0 + wc * WCO + b * 16 + fr;
@@ -372,7 +379,7 @@ void launch_stg(const WgradParams& p, hipStream_t stream) {
   const int tilesC = (p.Cout + BCO - 1) / BCO;
   const bool pointwise = p.TI == 1 && p.TJ == 1 && p.ISH == 1 && p.ISW == 1 && p.dh0 == 0 &&
                          p.dw0 == 0 && p.OH == p.H && p.OW == p.W && p.Ctap <= p.Cpix;
-  dim3 grid(tilesK * tilesC, p.splits);
+  dim3 grid(tilesK * tilesC, p.splits, p.batch ? p.nbatch : 1);
   if (pointwise)
     hipLaunchKernelGGL((conv_wgrad_kernel<DT, BKK, BCO, WAVES_K, WAVES_C, G, true, STAGES>), grid,
                        dim3(64 * WAVES_K * WAVES_C * G), 0, stream, p);
@@ -427,7 +434,8 @@ void launch_cfg(const WgradParams& p, int groups, int stages, hipStream_t stream
 
 void validate_wgrad_params(const WgradParams& p) {
   auto fail = [](const std::string& m) { throw std::invalid_argument("conv_wgrad: " + m); };
-  if (!p.x || !p.dy || !p.dw) fail("null tensor pointer");
+  if (p.batch == nullptr && (!p.x || !p.dy || !p.dw)) fail("null tensor pointer");
+  if (p.batch != nullptr && (p.nbatch < 1 || p.nbatch > 1024)) fail("1..1024 layers per batched launch");
   if (p.dt != DT_BF16 && p.dt != DT_F16 && p.dt != DT_F32) fail("unknown element type");
   if (p.P != p.N * p.OH * p.OW || p.P <= 0) fail("P != N*OH*OW");
   if ((int64_t)p.N * p.H * p.W >= (1ll << 31) / 8) fail("input too large for 32-bit pixel index");

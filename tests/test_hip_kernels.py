@@ -119,6 +119,23 @@ PIPE_CFGS = list(range(16, 32))
 def test_conv_pipeline_cfgs(case, cfg):
   """Every tile configuration of the multi-stage kernel (conv_pipe.hip): forward, data gradient
   and accumulate mode against fp32 PyTorch on the same bf16-rounded operands."""
+  _check_conv_cfg(case, cfg)
+
+
+@pytest.mark.parametrize("cfg", [8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("case", [
+    # ring variants of the general kernel: gathers whose K-steps straddle taps (the CIFAR
+    # stages), tap loops, pointwise, strided; 1 .. 18 K-steps, ragged M and Cout
+    (3, 32, 32, 16, 3, 16, 1), (5, 16, 16, 32, 3, 32, 1), (3, 8, 8, 64, 3, 64, 1),
+    (3, 17, 17, 16, 3, 32, 2), (2, 15, 13, 24, 3, 40, 1), (4, 9, 9, 8, 1, 16, 1),
+    (2, 16, 16, 32, 1, 64, 2), (3, 13, 11, 72, 1, 24, 1),
+])
+def test_conv_ring_cfgs(case, cfg):
+  """`conv_igemm.hip` with a ring of 4 / 6 LDS stages (tile configurations 8-13)."""
+  _check_conv_cfg(case, cfg)
+
+
+def _check_conv_cfg(case, cfg):
   native = _native()
   N, H, W, Cin, K, Cout, stride = case
   dev = torch.device("cuda")
@@ -159,7 +176,9 @@ def test_conv_pipeline_cfgs(case, cfg):
     (3, 17, 17, 16, 3, 16, 2, 3), (2, 14, 14, 256, 1, 512, 1, 4), (4, 28, 28, 128, 1, 64, 1, 5),
     (2, 9, 9, 32, 3, 72, 1, 0), (3, 28, 28, 64, 3, 128, 1, 6), (5, 14, 14, 256, 1, 200, 1, 6),
     (3, 28, 28, 64, 3, 128, 1, 16), (5, 14, 14, 256, 1, 200, 1, 17), (4, 28, 28, 128, 1, 64, 1, 21),
-    (4, 28, 28, 64, 1, 64, 1, 23), (2, 14, 14, 256, 1, 512, 1, 25), (3, 28, 28, 64, 3, 128, 1, 20)])
+    (4, 28, 28, 64, 1, 64, 1, 23), (2, 14, 14, 256, 1, 512, 1, 25), (3, 28, 28, 64, 3, 128, 1, 20),
+    (3, 17, 17, 16, 3, 16, 1, 8), (3, 17, 17, 16, 3, 32, 1, 9), (4, 16, 16, 32, 3, 64, 1, 10),
+    (4, 16, 16, 32, 3, 64, 1, 11), (3, 17, 17, 16, 3, 16, 1, 12), (3, 17, 17, 32, 3, 32, 1, 13)])
 def test_conv_fused_bn_statistics(case):
   """The epilogue's per-channel sum / sum of squares equal those of the stored bf16 output,
   followed by the BatchNorm finalize that consumes the replicas."""
@@ -809,3 +828,35 @@ def test_batchnorm_backward_reduction_finalised_by_its_last_block(P, C, dual):
     assert torch.allclose(outs[mode][1], outs["plain"][1], rtol=2e-2, atol=2e-2)
     if dual:
       assert torch.allclose(outs[mode][2], outs["plain"][2], rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("shape,cfg,splits", [((16, 32, 32, 16, 3, 16, 1), 5, 4),
+                                              ((16, 16, 16, 32, 3, 32, 1), 6, 2),
+                                              ((8, 14, 14, 64, 1, 128, 1), 2, 2)])
+def test_batched_weight_gradient_launch(shape, cfg, splits):
+  """One launch, one grid z-slice per layer: the weight gradients of five layers of identical
+  geometry from a device table of (x, dy, dw) pointers equal the five separate launches."""
+  native = _native()
+  N, H, W, Cin, K, Cout, stride = shape
+  dev = torch.device("cuda")
+  gen = torch.Generator(device="cpu").manual_seed(H + Cin)
+  pad = same_padding(H, K, stride) + same_padding(W, K, stride)
+  g = ConvGeom(N, H, W, Cin, K, K, Cout, stride, pad)
+  L = 5
+  xs = [_bf(torch.randn(N, H, W, Cin, generator=gen)).to(dev) for _ in range(L)]
+  dys = [_bf(torch.randn(N, g.OH, g.OW, Cout, generator=gen)).to(dev) for _ in range(L)]
+  one = [torch.zeros(K, K, Cin, Cout, dtype=torch.float32, device=dev) for _ in range(L)]
+  for x, dy, dw in zip(xs, dys, one):
+    native.run_op("wgrad", g.wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), cfg=cfg, splits=splits))
+  many = [torch.zeros(K, K, Cin, Cout, dtype=torch.float32, device=dev) for _ in range(L)]
+  table = torch.tensor([[x.data_ptr(), dy.data_ptr(), dw.data_ptr()] for x, dy, dw in zip(xs, dys, many)],
+                       dtype=torch.int64, device=dev)
+  d = g.wgrad(xs[0].data_ptr(), dys[0].data_ptr(), many[0].data_ptr(), cfg=cfg, splits=splits)
+  d.update(batch=table.data_ptr(), nbatch=L)
+  native.run_op("wgrad", d)
+  torch.cuda.synchronize()
+  for i, (a, b) in enumerate(zip(many, one)):
+    wr = torch.zeros(K, K, Cin, Cout, device=dev).requires_grad_(True)
+    _ref_conv(xs[i].float(), wr, stride, pad).backward(dys[i].float())
+    assert (a - wr.grad).abs().max().item() <= 0.01 * wr.grad.abs().max().item() + 1e-2
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-3 * b.abs().max().item())
