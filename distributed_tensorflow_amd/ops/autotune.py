@@ -25,7 +25,7 @@ __all__ = ["signature", "lookup", "apply", "tune", "save", "enabled", "CACHE_PAT
 
 CACHE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
 _POINTERS = ("in", "wgt", "out", "addend", "addend_mask", "bias", "stats", "stats_y",
-             "stats_mask", "x", "dy", "dw")
+             "stats_mask", "x", "dy", "dw", "scale", "batch")
 _IGNORED = _POINTERS + ("cfg", "splits", "stats_replicas")
 _cache: Optional[Dict[str, Dict[str, int]]] = None
 _dirty = False
@@ -53,10 +53,13 @@ def signature(kind: str, desc: Dict) -> str:
     if k in _IGNORED:
       continue
     parts.append("%s=%s" % (k, desc[k]))
-  for k in ("addend", "addend_mask", "bias", "stats"):
+  for k in ("addend", "addend_mask", "bias", "stats", "scale"):
     if desc.get(k) is not None:
       if k == "stats" and desc.get("stats_y") is not None:
-        continue      # backward statistics ride on a data gradient: tuned as the plain launch
+        # backward statistics in a data-gradient epilogue (re-reads the BatchNorm input):
+        # a different kernel from the plain launch, and measured as such
+        parts.append("+bstats")
+        continue
       parts.append("+" + k)
   return "|".join(parts)
 
