@@ -78,13 +78,13 @@ def lookup(kind: str, desc: Dict) -> Optional[Dict[str, int]]:
 def _fwd_candidates(desc: Dict) -> List[int]:
   cout = desc["Cout"]
   if cout <= 16:
-    return [3, 2, 8, 12]
+    return [3, 2, 8, 12, 7, 33]
   if cout <= 32:
-    return [2, 1, 9, 13]
+    return [2, 1, 9, 13, 15, 7, 32, 34]
   # 16..: the multi-stage pipeline of conv_pipe.hip (descriptors it cannot serve fall back to
   # the two-stage tile of the same footprint, so listing them is always safe)
   if cout <= 64:
-    return [1, 5, 0, 21, 22, 23, 20, 10, 11]
+    return [1, 5, 0, 21, 22, 23, 20, 10, 11, 14, 15, 32, 34]
   wide = [29, 30, 31] if cout >= 256 else []       # 256 output channels per block
   return [0, 6, 4, 5, 1, 16, 17, 18, 19, 20, 21, 24, 25, 26, 27, 28] + wide
 

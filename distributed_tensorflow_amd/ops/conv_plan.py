@@ -26,14 +26,15 @@ __all__ = ["ConvGeom", "round_up", "pick_fwd_cfg", "pick_wgrad_cfg"]
 
 # tile configurations compiled into the extension: cfg id -> (BM pixels, BN channels)
 FWD_CFGS = {0: (128, 128), 1: (256, 64), 2: (256, 32), 3: (256, 16), 4: (64, 128), 5: (128, 64),
-            6: (256, 128),
+            6: (256, 128), 7: (128, 16), 14: (64, 64), 15: (128, 32),
             # ring of 4 / 6 LDS stages on any gather (short, tap-straddling reductions)
             8: (256, 16), 9: (256, 32), 10: (128, 64), 11: (256, 64), 12: (128, 16), 13: (128, 32),
             # multi-stage pipeline (conv_pipe.hip): (BM, BN); K-step and ring depth vary
             16: (256, 128), 17: (256, 128), 18: (128, 128), 19: (128, 128), 20: (128, 128),
             21: (128, 64), 22: (256, 64), 23: (256, 64), 24: (64, 128), 25: (128, 256),
             26: (256, 128), 27: (128, 128), 28: (256, 128), 29: (256, 256), 30: (256, 256),
-            31: (128, 256)}
+            31: (128, 256),
+            32: (64, 32), 33: (64, 16), 34: (64, 32)}
 # cfg id % 16 -> (BKK rows of dW, BCO output channels); (cfg id % 64) // 16 = log2(wave groups per
 # block); cfg id // 64 = LDS ring depth - 2 (conv_wgrad.hip)
 WGRAD_CFGS = {0: (128, 128), 1: (128, 64), 2: (64, 128), 3: (64, 64), 4: (128, 32),

@@ -498,12 +498,12 @@ void validate_conv_params(const ConvParams& p) {
   }
 }
 
-// cfg 0..15: the two-stage kernel of this file; cfg 16..: the multi-stage pipeline of
+// cfg 0..15 and 32..: the kernel of this file; cfg 16..31: the multi-stage pipeline of
 // conv_pipe.hip, which hands descriptors that need the generic gather back to the tile of
 // this file with the same footprint.
 void launch_conv_igemm(const ConvParams& p, int cfg, hipStream_t stream) {
   validate_conv_params(p);
-  if (cfg >= 16) {
+  if (cfg >= 16 && cfg < 32) {
     if (p.dt == DT_BF16 && launch_conv_pipe(p, cfg, stream)) return;
     cfg = pipe_fallback_cfg(cfg);
   }
@@ -515,6 +515,13 @@ void launch_conv_igemm(const ConvParams& p, int cfg, hipStream_t stream) {
     case 4: launch_cfg<64, 128, 1, 4>(p, stream); break;
     case 5: launch_cfg<128, 64, 2, 2>(p, stream); break;
     case 6: launch_cfg<256, 128, 4, 2>(p, stream); break;   // 8 waves: 1.5x the FLOP per L2 byte
+    // small tiles: more blocks for the latency-bound layers of the CIFAR ResNets
+    case 7: launch_cfg<128, 16, 4, 1>(p, stream); break;
+    case 14: launch_cfg<64, 64, 2, 2>(p, stream); break;
+    case 15: launch_cfg<128, 32, 4, 1>(p, stream); break;
+    case 32: launch_cfg<64, 32, 4, 1>(p, stream); break;
+    case 33: launch_cfg<64, 16, 4, 1>(p, stream); break;
+    case 34: launch_cfg<64, 32, 2, 2>(p, stream); break;
     //                       BM   BN  WM WN  ring          LDS, blocks / CU
     case 8: launch_ring<256, 16, 4, 1, 4>(p, stream); break;    // 68 KiB, 2
     case 9: launch_ring<256, 32, 4, 1, 4>(p, stream); break;    // 72 KiB, 2

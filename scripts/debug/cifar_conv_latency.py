@@ -8,7 +8,7 @@ from distributed_tensorflow_amd.ops.conv_plan import ConvGeom
 from distributed_tensorflow_amd.models.graph import same_padding
 dev = torch.device("cuda")
 N = 128
-for (H, C, cfgs) in ((32, 16, [3, 2, 8, 12]), (16, 32, [2, 1, 9, 13]), (8, 64, [5, 1, 0, 10, 11, 21, 23, 20])):
+for (H, C, cfgs) in ((32, 16, [3, 7, 33]), (16, 32, [2, 15, 7, 32, 33, 34]), (8, 64, [5, 21, 14, 15, 32, 34])):
   pad = same_padding(H, 3, 1) + same_padding(H, 3, 1)
   g = ConvGeom(N, H, H, C, 3, 3, C, 1, pad)
   x = torch.randn(N, H, H, C, device=dev).to(torch.bfloat16)

@@ -122,7 +122,7 @@ def test_conv_pipeline_cfgs(case, cfg):
   _check_conv_cfg(case, cfg)
 
 
-@pytest.mark.parametrize("cfg", [8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("cfg", [7, 8, 9, 10, 11, 12, 13, 14, 15, 32, 33, 34])
 @pytest.mark.parametrize("case", [
     # ring variants of the general kernel: gathers whose K-steps straddle taps (the CIFAR
     # stages), tap loops, pointwise, strided; 1 .. 18 K-steps, ragged M and Cout
