@@ -120,8 +120,10 @@ def define_keras_flags(dynamic_loss_scale=True):
                    "flag given the buckets are 25 MB).")
   f.DEFINE_boolean("use_hip_graph", True, "Replay the training step as a captured hipGraph "
                    "when the strategy allows it.")
-  f.DEFINE_boolean("deterministic", False, "Fixed-order BatchNorm statistics, and a check "
-                   "that replicas hold identical gradients after the all-reduce (debug aid).")
+  f.DEFINE_boolean("deterministic", False, "Every floating-point sum of a step in a fixed order "
+                   "(BatchNorm statistics, weight and bias gradients: two runs agree bit for "
+                   "bit; slower), and a check that replicas hold identical gradients after the "
+                   "all-reduce (debug aid).")
 
 
 def data_delay_prefetch():

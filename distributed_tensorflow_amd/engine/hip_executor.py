@@ -108,7 +108,7 @@ class HipExecutor:
 
   def __init__(self, spec: ModelSpec, store: ParamStore, batch_size: int, dtype: str = "bf16",
                buckets: Optional[List[Bucket]] = None, use_graph: Optional[bool] = None,
-               fused_bn_stats: Optional[bool] = None):
+               fused_bn_stats: Optional[bool] = None, deterministic: bool = False):
     if store.device.type != "cuda":
       raise RuntimeError("HipExecutor needs a GPU device")
     if dtype not in ELEMENT_TYPES:
@@ -139,6 +139,14 @@ class HipExecutor:
     # BatchNorm statistics accumulated in the convolution epilogue with float atomics (one
     # sweep over the activations less, summation order not fixed) or by the separate
     # deterministic sweep
+    # deterministic: every floating-point sum of the step has a fixed order - BatchNorm
+    # statistics by the partial-row sweeps, weight gradients without a split of the pixel range
+    # (one block per output tile: its single atomic add lands on a zeroed element), bias
+    # gradients by one block per column group.  Slower (a 1x1 layer with 64 input channels has
+    # two weight-gradient tiles for 800 000 pixels); two runs then agree bit for bit.
+    self.deterministic = bool(deterministic)
+    if self.deterministic:
+      fused_bn_stats = False
     if fused_bn_stats is None:
       fused_bn_stats = os.environ.get("DTF_BN_FUSED_STATS", "1") != "0"
     self.fused_bn_stats = fused_bn_stats and self.dt == 0
@@ -470,6 +478,8 @@ class HipExecutor:
     """plan.add with the measured tile configuration of this shape, when one is known."""
     if kind in ("conv", "wgrad"):
       desc = autotune.apply(kind, desc)
+    if kind == "wgrad" and self.deterministic:
+      desc = dict(desc, splits=1)
     plan.add(kind, desc, name, lane)
 
   def _add_wgrad(self, plan, desc: Dict, name: str):
@@ -807,7 +817,8 @@ class HipExecutor:
       if op.kind == "dense":
         g = self.geoms[op.name]
         plan.add("colsum", dict(x=dout.data_ptr(), out=self._var_ptr(op.name + "/bias", "grad"),
-                                N=N, C=g.Cout, ld=g.ldc), op.name + "/dbias")
+                                N=N, C=g.Cout, ld=g.ldc, slices=1 if self.deterministic else 0),
+                 op.name + "/dbias")
         self._add_wgrad(plan, g.wgrad(acts[xname].data_ptr(), dout.data_ptr(),
                                       self._var_ptr(op.name + "/kernel", "grad")),
                         op.name + "/wgrad")

@@ -279,7 +279,8 @@ Launch make_op(const std::string& kind, const py::dict& d) {
   if (kind == "colsum") {
     auto x = ptr<const void>(d, "x"); auto out = ptr<float>(d, "out");
     const int N = get<int>(d, "N"), C = get<int>(d, "C"), ld = get<int>(d, "ld");
-    return [=](hipStream_t s) { launch_colsum(x, out, N, C, ld, dt, s); };
+    const int slices = get_or<int>(d, "slices", 0);
+    return [=](hipStream_t s) { launch_colsum(x, out, N, C, ld, dt, slices, s); };
   }
   if (kind == "sgd") {
     auto p = ptr<float>(d, "p"); auto g = ptr<const float>(d, "g"); auto v = ptr<float>(d, "v");

@@ -67,7 +67,8 @@ void launch_softmax_xent(const void* logits, const int32_t* labels, void* dlogit
                          const float* grad_scale_dev, int dt, hipStream_t s);
 void launch_softmax_probs(const void* logits, float* probs, int N, int C, int ld, int dt,
                           hipStream_t s);
-void launch_colsum(const void* x, float* out, int N, int C, int ld, int dt, hipStream_t s);
+void launch_colsum(const void* x, float* out, int N, int C, int ld, int dt, int slices_req,
+                   hipStream_t s);
 
 // Dense layers of any shape on fp32 master weights [in, out] (dense.hip).
 void launch_dense_fwd(const void* x, const float* w, const float* bias, void* out, int N, int K,

@@ -136,8 +136,10 @@ void launch_softmax_probs(const void* logits, float* probs, int N, int C, int ld
                                        (float*)nullptr, N, C, ld, 1.f, (const float*)nullptr));
 }
 
-void launch_colsum(const void* x, float* out, int N, int C, int ld, int dt, hipStream_t s) {
-  const int slices = N >= 64 ? 64 : (N > 0 ? N : 1);
+void launch_colsum(const void* x, float* out, int N, int C, int ld, int dt, int slices_req,
+                   hipStream_t s) {
+  // slices_req > 0: that many row slices (1: a fixed summation order, one block per column group)
+  const int slices = slices_req > 0 ? slices_req : (N >= 64 ? 64 : (N > 0 ? N : 1));
   DTF_DT_SWITCH(dt, hipLaunchKernelGGL(colsum_kernel<DT>, dim3((C + 255) / 256, slices), dim3(256),
                                        0, s, x, out, N, C, ld));
 }

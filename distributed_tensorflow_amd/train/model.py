@@ -80,7 +80,8 @@ class Model:
                executor: str = "auto", data_format: str = "channels_last",
                use_hip_graph: Optional[bool] = None, deterministic: bool = False):
     """`use_hip_graph`: replay the native training step as a captured hipGraph (None: the
-    executor's default).  `deterministic`: fixed-order BatchNorm statistics, and after every
+    executor's default).  `deterministic`: every sum of the step in a fixed order (BatchNorm
+    statistics, weight gradients, bias gradients: two runs agree bit for bit), and after every
     gradient all-reduce the replicas compare a checksum of the reduced gradients."""
     self.spec = spec
     self.name = spec.name
@@ -164,7 +165,8 @@ class Model:
           use_graph = False
         ex = HipExecutor(self.spec, self.store, batch, self.dtype, self._bucket_list(),
                          use_graph=use_graph,
-                         fused_bn_stats=False if self.deterministic else None)
+                         fused_bn_stats=False if self.deterministic else None,
+                         deterministic=self.deterministic)
       else:
         ex = TorchExecutor(self.spec, self.store, batch, self.dtype, self._bucket_list(),
                            data_format=self.data_format)

@@ -460,3 +460,37 @@ def test_dynamic_loss_scale_is_decided_on_the_device():
   assert not torch.equal(sa.params, before)
   # another executor (different batch size) is handed the value
   assert dyn_dev.loss_scale_for(eb) == 512.0
+
+
+def test_deterministic_mode_is_bitwise_reproducible():
+  """`--deterministic`: BatchNorm statistics by fixed-order sweeps, weight gradients without a
+  split of the pixel range, bias gradients by one block per column group - three training
+  steps of two independent runs end in bit-identical parameters, momentum and moving
+  statistics (the default mode accumulates with float atomics and does not)."""
+  from distributed_tensorflow_amd.engine.hip_executor import HipExecutor
+  from distributed_tensorflow_amd.engine.params import ParamStore
+  from distributed_tensorflow_amd.ops import fused
+  dev = torch.device("cuda")
+  spec = models.resnet20()
+  g = torch.Generator().manual_seed(21)
+  x = torch.randn(32, 32, 32, 3, generator=g).to(dev)
+  y = torch.randint(0, 10, (32,), generator=g).to(dev)
+
+  def run(deterministic):
+    store = ParamStore(spec, dev, 4)
+    hx = HipExecutor(spec, store, 32, "bf16", store.make_buckets(1), use_graph=False,
+                     deterministic=deterministic)
+    for _ in range(3):
+      hx.train_step(x, y, 1.0)
+      fused.sgd_momentum_l2(store.params, store.grads, store.slot("momentum"), store.l2_vector(),
+                            0.05, 0.9, 1.0)
+      store.version += 1
+      hx.params_updated()
+    torch.cuda.synchronize()
+    return store.params.clone(), store.slot("momentum").clone(), store.state.clone()
+
+  a, b = run(True), run(True)
+  for u, v in zip(a, b):
+    assert torch.equal(u, v)
+  c = run(False)
+  assert torch.allclose(a[0], c[0], rtol=0, atol=5e-2)        # same training, different rounding
