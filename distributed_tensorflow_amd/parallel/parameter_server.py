@@ -21,7 +21,7 @@ posts its transfers in the order of its requests.
 
 Requests:
 
-* `pull:<rank>:<fmt>` - PS -> worker: the parameter shard as fp32 or bfloat16
+* `pull:<rank>:<fmt>[:fresh]` - PS -> worker: the parameter shard as fp32 or bfloat16
   (a 16-bit worker would round the fp32 values the same way itself; half the
   bytes), PS 0 also the BatchNorm moving statistics.
 * `push:<rank>:<lr>:<divisor>:<fmt>:<lo>-<hi>,...` - worker -> PS: the gradient
@@ -262,7 +262,12 @@ class ParameterServerStrategy(Strategy):
   def _shards(self, store):
     return shard_ranges(store.num_elements, self.num_ps)
 
-  def _start_pull(self, store, fmt: str):
+  def flush(self):
+    """Returns when every transfer this worker has announced has left (its last push included)."""
+    if self._last_send is not None:
+      self._last_send.result()
+
+  def _start_pull(self, store, fmt: str, fresh: bool = False):
     """Posts the pull requests and queues the receives on the receiving lane; returns the
     future of the lane task, whose result is the list of filled landing buffers."""
     dtype = torch.bfloat16 if fmt == "bf16" else torch.float32
@@ -270,7 +275,7 @@ class ParameterServerStrategy(Strategy):
     dev = store.device
     staged = self._staged(dev)
     for k in range(self.num_ps):
-      self._post(k, "pull:%d:%s" % (self.comm.rank, fmt))
+      self._post(k, "pull:%d:%s%s" % (self.comm.rank, fmt, ":fresh" if fresh else ""))
     consumed = self._h2d_done
 
     def task():
@@ -323,9 +328,8 @@ class ParameterServerStrategy(Strategy):
       pre[0].result()            # the PS is sending it anyway: receive and drop
       pre = None
     if pre is None:
-      if self._last_send is not None:
-        self._last_send.result()
-      pre = (self._start_pull(store, fmt), fmt)
+      self.flush()
+      pre = (self._start_pull(store, fmt, fresh), fmt)
     t0 = time.time()
     landed = pre[0].result()
     self.wait_s["pull"] += time.time() - t0
@@ -581,8 +585,10 @@ class ParameterServerStrategy(Strategy):
       if op == "pull":
         # read-your-writes for the requesting worker; other workers' pushes are applied first
         # only when they have arrived completely
+        # (a `fresh` pull - evaluation, checkpoints - waits for every push that has been announced)
+        fresh = len(parts) > 3 and parts[3] == "fresh"
         for p in list(inflight):
-          if p["src"] == src or all(w.is_completed() for w in p["works"]):
+          if fresh or p["src"] == src or all(w.is_completed() for w in p["works"]):
             inflight.remove(p)
             finalize(p)
         dtype = torch.bfloat16 if (len(parts) > 2 and parts[2] == "bf16") else torch.float32

@@ -372,8 +372,9 @@ else:
   out["scale"] = opt.scale
   out["skipped"] = opt.skipped_steps
   out["buckets"] = len(m._bucket_list())
-  # wait until every worker is done pushing, then read the ps copies back
+  # wait until every worker's pushes have left, then read the ps copies back
   st = strat._store
+  strat.flush()
   st.add("test/finished", 1)
   import time
   while int(st.add("test/finished", 0)) < strat.num_workers:
