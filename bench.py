@@ -183,6 +183,9 @@ def main() -> int:
                        " (one-rank collective rehearsal)" if a.rehearse_collectives and a.gpus == 1
                        else ""),
                    "executor": model.executor_kind, "launch": launch_mode,
+                   "collectives": ("none" if strat is None else
+                                   "native RCCL communicator" if getattr(model._reducer, "_native", None)
+                                   else "torch.distributed (%s)" % strat.comm.backend),
                    "final_loss": round(loss_val, 4),
                    "baseline_img_per_sec": baseline_for(a.gpus)}}
     sys.stdout.flush()

@@ -22,6 +22,7 @@
 #include "common.h"
 #include "conv_params.h"
 #include "elementwise.h"
+#include "rccl_comm.h"
 
 namespace py = pybind11;
 using Launch = std::function<void(hipStream_t)>;
@@ -341,6 +342,20 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     const size_t n = get<size_t>(d, "n");
     return [=](hipStream_t s) { launch_cast_from_f32(in, out, n, dt, s); };
   }
+  if (kind == "allreduce") {
+    // a collective as a plan entry: `comm` is the address of a live RcclComm (kept alive by its
+    // Python owner); mode 0 one-shot, 1 reduce-scatter + all-gather, 2 by message size
+    auto* comm = reinterpret_cast<dtf::RcclComm*>(get<uintptr_t>(d, "comm"));
+    auto buf = ptr<void>(d, "buf");
+    const size_t count = get<size_t>(d, "count");
+    const int mode = get_or<int>(d, "mode", 2);
+    if (!comm) throw std::invalid_argument("allreduce: null communicator");
+    return [=](hipStream_t s) {
+      if (mode == 0) comm->all_reduce(buf, count, dt, s);
+      else if (mode == 1) comm->all_reduce_direct(buf, count, dt, s);
+      else comm->all_reduce_auto(buf, count, dt, s);
+    };
+  }
   if (kind == "memset") {
     auto p = ptr<uint8_t>(d, "ptr");
     const size_t n = get<size_t>(d, "nbytes");
@@ -612,6 +627,48 @@ PYBIND11_MODULE(_dtf_native, m) {
         "before (the plans' side lane included); lives as long as the process.");
   m.def("last_lane_probe", []() { return lane_registry().last_probe(); },
         "Overlap ratios measured by the most recent lane pick (1: concurrent, 2: serialised).");
+  py::class_<dtf::RcclComm>(m, "RcclComm")
+      .def(py::init([](py::bytes id, int nranks, int rank) {
+             return new dtf::RcclComm(std::string(id), nranks, rank);
+           }), py::arg("unique_id"), py::arg("nranks"), py::arg("rank"))
+      .def_static("unique_id", []() { return py::bytes(dtf::RcclComm::unique_id()); })
+      .def_static("load_library", &dtf::RcclComm::load_library)
+      .def_static("group_start", &dtf::RcclComm::group_start)
+      .def_static("group_end", &dtf::RcclComm::group_end)
+      .def_property_readonly("rank", &dtf::RcclComm::rank)
+      .def_property_readonly("size", &dtf::RcclComm::size)
+      .def_property_readonly("handle", [](dtf::RcclComm& c) { return reinterpret_cast<uintptr_t>(&c); })
+      .def_readwrite("direct_min_bytes", &dtf::RcclComm::direct_min_bytes)
+      .def_readonly("collectives", &dtf::RcclComm::collectives)
+      .def("all_reduce", [](dtf::RcclComm& c, uintptr_t p, size_t n, int dt, uintptr_t s) {
+             c.all_reduce(reinterpret_cast<void*>(p), n, dt, reinterpret_cast<hipStream_t>(s)); },
+           py::arg("ptr"), py::arg("count"), py::arg("dt") = 2, py::arg("stream") = 0)
+      .def("all_reduce_direct", [](dtf::RcclComm& c, uintptr_t p, size_t n, int dt, uintptr_t s) {
+             c.all_reduce_direct(reinterpret_cast<void*>(p), n, dt, reinterpret_cast<hipStream_t>(s)); },
+           py::arg("ptr"), py::arg("count"), py::arg("dt") = 2, py::arg("stream") = 0)
+      .def("all_reduce_auto", [](dtf::RcclComm& c, uintptr_t p, size_t n, int dt, uintptr_t s) {
+             c.all_reduce_auto(reinterpret_cast<void*>(p), n, dt, reinterpret_cast<hipStream_t>(s)); },
+           py::arg("ptr"), py::arg("count"), py::arg("dt") = 2, py::arg("stream") = 0)
+      .def("reduce_scatter", [](dtf::RcclComm& c, uintptr_t a, uintptr_t b, size_t n, int dt, uintptr_t s) {
+             c.reduce_scatter(reinterpret_cast<const void*>(a), reinterpret_cast<void*>(b), n, dt,
+                              reinterpret_cast<hipStream_t>(s)); },
+           py::arg("send"), py::arg("recv"), py::arg("recv_count"), py::arg("dt") = 2, py::arg("stream") = 0)
+      .def("all_gather", [](dtf::RcclComm& c, uintptr_t a, uintptr_t b, size_t n, int dt, uintptr_t s) {
+             c.all_gather(reinterpret_cast<const void*>(a), reinterpret_cast<void*>(b), n, dt,
+                          reinterpret_cast<hipStream_t>(s)); },
+           py::arg("send"), py::arg("recv"), py::arg("send_count"), py::arg("dt") = 2, py::arg("stream") = 0)
+      .def("broadcast", [](dtf::RcclComm& c, uintptr_t p, size_t n, int dt, int root, uintptr_t s) {
+             c.broadcast(reinterpret_cast<void*>(p), n, dt, root, reinterpret_cast<hipStream_t>(s)); },
+           py::arg("ptr"), py::arg("count"), py::arg("dt") = 2, py::arg("root") = 0, py::arg("stream") = 0)
+      .def("reduce", [](dtf::RcclComm& c, uintptr_t p, size_t n, int dt, int root, uintptr_t s) {
+             c.reduce(reinterpret_cast<void*>(p), n, dt, root, reinterpret_cast<hipStream_t>(s)); },
+           py::arg("ptr"), py::arg("count"), py::arg("dt") = 2, py::arg("root") = 0, py::arg("stream") = 0)
+      .def("send", [](dtf::RcclComm& c, uintptr_t p, size_t n, int dt, int peer, uintptr_t s) {
+             c.send(reinterpret_cast<const void*>(p), n, dt, peer, reinterpret_cast<hipStream_t>(s)); },
+           py::arg("ptr"), py::arg("count"), py::arg("dt"), py::arg("peer"), py::arg("stream") = 0)
+      .def("recv", [](dtf::RcclComm& c, uintptr_t p, size_t n, int dt, int peer, uintptr_t s) {
+             c.recv(reinterpret_cast<void*>(p), n, dt, peer, reinterpret_cast<hipStream_t>(s)); },
+           py::arg("ptr"), py::arg("count"), py::arg("dt"), py::arg("peer"), py::arg("stream") = 0);
   m.def("fastdiv_check", [](uint32_t n, uint32_t d) { return fd_div(n, make_fastdiv(d)); });
   m.def("pack_desc_size", []() { return (int)sizeof(PackDesc); });
   m.def("bn_workspace_floats", []() { return bn_workspace_floats(); });

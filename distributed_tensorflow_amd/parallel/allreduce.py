@@ -61,6 +61,7 @@ class GradientReducer:
     self._stream_pending = False
     self._side = None              # the executor's side lane, when it orders its results here
     self._executor = None          # set by orders_side_lane()
+    self._native = None            # the engine's own RCCL communicator (DTF_COMM=native)
     self.bytes_reduced = 0
     self.collectives_launched = 0
 
@@ -114,9 +115,30 @@ class GradientReducer:
     self._executor = executor
     return True
 
+  def _native_comm(self):
+    """The engine's own RCCL communicator when `DTF_COMM=native` asks for it (GPU jobs)."""
+    if self._native is None:
+      self._native = False
+      if os.environ.get("DTF_COMM", "torch") == "native" and self.comm.backend == "nccl":
+        from .rccl import get_native_comm  # pylint: disable=import-outside-toplevel
+        self._native = get_native_comm(self.comm) or False
+    return self._native or None
+
   def _issue(self, g: torch.Tensor, async_op: bool):
     """The bucket's collective(s); returns the last work handle (None for blocking calls)."""
     c = self.comm
+    nat = self._native_comm() if g.is_cuda else None
+    if nat is not None:
+      # stream-ordered on torch's current stream (the reducer's communication stream, or the
+      # compute stream for a single bucket): nothing to wait for on the host
+      if self.alg == "hierarchical_copy":
+        nat.reduce(g, 0)
+        nat.broadcast(g, 0)
+        self.collectives_launched += 2
+      else:
+        nat.all_reduce(g, "direct" if self.alg == "ring" else "auto")
+        self.collectives_launched += 1
+      return None
     if self.alg == "ring" and c.supports_reduce_scatter() and g.numel() % self.n == 0:
       shard = g.numel() // self.n
       r = c.rank if self.group is None else torch.distributed.get_rank(self.group)
