@@ -184,6 +184,8 @@ def main() -> int:
                        else ""),
                    "executor": model.executor_kind, "launch": launch_mode,
                    "collectives": ("none" if strat is None else
+                                   "native RCCL communicator, all-reduce inside the launch plan"
+                                   if getattr(model._reducer, "_skip", False) else
                                    "native RCCL communicator" if getattr(model._reducer, "_native", None)
                                    else "torch.distributed (%s)" % strat.comm.backend),
                    "final_loss": round(loss_val, 4),

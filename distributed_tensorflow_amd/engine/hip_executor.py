@@ -1068,6 +1068,19 @@ class HipExecutor:
       for b in ready:
         on_bucket_ready(b)
 
+  def attach_collective(self, desc: Dict) -> bool:
+    """Appends a collective of the native communicator (`allreduce` plan entry over the whole
+    gradient buffer) to the end of the backward plan: a model whose gradients are one bucket
+    then reduces them from inside the plan - and inside the captured hipGraph - with no host
+    call between backward and optimizer.  Only before the first graph capture."""
+    if self._train_graph is not None or getattr(self, "collective_in_plan", False):
+      return getattr(self, "collective_in_plan", False)
+    self.bwd_plan.add("allreduce", desc, "gradients/allreduce", 0)
+    begin, _end, ready = self._segments[-1]
+    self._segments[-1] = (begin, self.bwd_plan.size(), ready)
+    self.collective_in_plan = True
+    return True
+
   def side_stream(self) -> Optional["torch.cuda.Stream"]:
     """The plans' side lane (weight gradients), once it exists."""
     h = native.ext().Plan.side_stream()

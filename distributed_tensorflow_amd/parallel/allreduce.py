@@ -62,6 +62,8 @@ class GradientReducer:
     self._side = None              # the executor's side lane, when it orders its results here
     self._executor = None          # set by orders_side_lane()
     self._native = None            # the engine's own RCCL communicator (DTF_COMM=native)
+    self._in_plan = set()          # executors whose backward plan ends with the collective
+    self._skip = False
     self.bytes_reduced = 0
     self.collectives_launched = 0
 
@@ -124,6 +126,26 @@ class GradientReducer:
         self._native = get_native_comm(self.comm) or False
     return self._native or None
 
+  def attach_to_plan(self, executor) -> bool:
+    """Small-message policy, native communicator: the single bucket's all-reduce becomes the last
+    entry of the executor's backward plan (captured with it); `on_bucket_ready` / `finish` then
+    have nothing left to do for that executor.  False when this reducer or executor cannot."""
+    if executor in self._in_plan:
+      return True
+    if (len(self.buckets) != 1 or not hasattr(executor, "attach_collective")
+        or self.alg == "hierarchical_copy"
+        or (self.n <= 1 and not getattr(self.comm, "rehearse", False))
+        or os.environ.get("DTF_COMM_IN_PLAN", "1") == "0"):
+      return False
+    nat = self._native_comm()
+    if nat is None:
+      return False
+    g = self._slice(self.buckets[0])
+    if executor.attach_collective(nat.plan_entry(g, "direct" if self.alg == "ring" else "auto")):
+      self._in_plan.add(executor)
+      return True
+    return False
+
   def _issue(self, g: torch.Tensor, async_op: bool):
     """The bucket's collective(s); returns the last work handle (None for blocking calls)."""
     c = self.comm
@@ -161,6 +183,9 @@ class GradientReducer:
 
   def on_bucket_ready(self, b: Bucket):
     if self.n <= 1 and not getattr(self.comm, "rehearse", False):
+      return
+    if self._skip:                 # the running executor's plan contains the collective
+      self.bytes_reduced += (b.end - b.start) * 4
       return
     g = self._slice(b)
     c = self.comm

@@ -250,6 +250,8 @@ class Model:
       self.optimizer.iterations += 1
       return loss, correct
     red = self._grad_reducer()
+    if red is not None and getattr(ex, "native", False) and hasattr(red, "attach_to_plan"):
+      red._skip = red.attach_to_plan(ex)          # single bucket + native communicator
     if red is not None and getattr(ex, "native", False) and \
         getattr(red, "orders_side_lane", None) is not None and red.orders_side_lane(ex):
       loss, correct = ex.train_step(images, idx, self._loss_scale(ex), red.on_bucket_ready,

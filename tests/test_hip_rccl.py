@@ -86,3 +86,16 @@ def test_reducer_on_the_native_communicator_in_a_one_rank_rehearsal(tmp_path):
   assert out["native"]["n_gpus"] == 1 and out["native"]["value"] > 0
   # the same training either way: the final losses of the two runs agree
   assert abs(out["native"]["config"]["final_loss"] - out["torch"]["config"]["final_loss"]) < 0.05
+
+
+def test_single_bucket_gradient_is_reduced_inside_the_launch_plan():
+  """Small-message policy with the native communicator: ResNet-20's gradient is one bucket, its
+  all-reduce is the last entry of the backward plan (and a node of the captured graph)."""
+  env = dict(os.environ, DTF_COMM="native")
+  r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "resnet20",
+                      "--batch", "64", "--steps", "12", "--warmup", "10", "--rehearse_collectives",
+                      "--num_packs", "1"], env=env, capture_output=True, text=True, timeout=300)
+  assert r.returncode == 0, r.stderr[-3000:]
+  out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+  assert out["config"]["collectives"] == "native RCCL communicator, all-reduce inside the launch plan"
+  assert 0 < out["config"]["final_loss"] < 10
