@@ -113,10 +113,10 @@ class HipExecutor:
       raise RuntimeError("HipExecutor needs a GPU device")
     if dtype not in ELEMENT_TYPES:
       raise ValueError("the native engine stores activations as bf16, fp16 or fp32 (got %s)" % dtype)
-    # bf16 is the type the engine is tuned for (fused statistics, folded inference BatchNorm,
-    # multi-stage pipelines); fp16 (the reference's mixed precision, with loss scaling) and fp32
-    # (the reference's default precision, exact fp32 matrix instructions) run the same plan on
-    # the same kernels instantiated for their element type, without those fusions
+    # bf16 is the type the engine is tuned for; fp16 (the reference's mixed precision, with loss
+    # scaling) runs the same kernels and fusions instantiated for IEEE half; fp32 (the
+    # reference's default precision, exact fp32 matrix instructions) runs the same plan without
+    # the fused statistics, the folded inference BatchNorm and the multi-stage pipelines
     self.dt, self.act_dtype = ELEMENT_TYPES[dtype]
     self.esize = torch.empty((), dtype=self.act_dtype).element_size()
     if not supports(spec):
@@ -149,7 +149,7 @@ class HipExecutor:
       fused_bn_stats = False
     if fused_bn_stats is None:
       fused_bn_stats = os.environ.get("DTF_BN_FUSED_STATS", "1") != "0"
-    self.fused_bn_stats = fused_bn_stats and self.dt == 0
+    self.fused_bn_stats = fused_bn_stats and self.dt in (0, 1)      # the 16-bit element types
     self.overlap_wgrad = os.environ.get("DTF_WGRAD_STREAM", "1") != "0"
     self.wgrad_group = int(os.environ.get("DTF_WGRAD_GROUP", "0"))   # 0: decided while planning
     # several layers' weight gradients in one launch: opt-in, fewer launches did not pay
@@ -658,8 +658,8 @@ class HipExecutor:
     returns {BatchNorm name: op} of the folded layers."""
     import struct
     spec, acts = self.spec, self.acts
-    if os.environ.get("DTF_EVAL_FOLD_BN", "1") == "0" or self.dt != 0:
-      return {}       # the folded epilogue exists for bfloat16 only
+    if os.environ.get("DTF_EVAL_FOLD_BN", "1") == "0" or self.dt == 2:
+      return {}       # the folded epilogue exists for the 16-bit element types
     consumers: Dict[str, int] = {}
     for op in spec.ops:
       for t in op.inputs:

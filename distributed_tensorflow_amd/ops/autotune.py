@@ -169,17 +169,25 @@ def tune(kind: str, desc: Dict) -> Dict[str, int]:
   if kind == "conv":
     for c in _fwd_candidates(desc):
       trial["cfg"] = c
-      t = _time_op(kind, trial)
+      try:
+        t = _time_op(kind, trial)
+      except ValueError:          # a configuration this descriptor (element type) cannot use
+        continue
       if t < best_t:
         best, best_t = {"cfg": c}, t
   elif kind == "wgrad":
     for c, s in _wgrad_candidates(desc):
       trial["cfg"], trial["splits"] = c, s
-      t = _time_op(kind, trial)
+      try:
+        t = _time_op(kind, trial)
+      except ValueError:
+        continue
       if t < best_t:
         best, best_t = {"cfg": c, "splits": s}, t
   else:
     raise ValueError("nothing to tune for op kind %r" % kind)
+  if best is None:
+    raise ValueError("no tile configuration accepts %s" % signature(kind, desc))
   best["us"] = round(best_t * 1000.0, 1)
   _retuned.add(signature(kind, desc))
   _load()[signature(kind, desc)] = best

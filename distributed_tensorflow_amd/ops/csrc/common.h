@@ -134,11 +134,45 @@ __device__ __forceinline__ void straw(void* base, size_t off, const float* f) {
   }
 }
 // Two fp32 values packed into one 32-bit word of 16-bit elements (16-bit types only).
+// the two 16-bit elements packed in a 32-bit word, as floats (bf16 / fp16 only)
+template <int DT>
+__device__ __forceinline__ float lo16(uint32_t w) {
+  if constexpr (DT == DT_BF16) return __uint_as_float(w << 16);
+  else return to_f<DT>((uint16_t)(w & 0xffffu));
+}
+template <int DT>
+__device__ __forceinline__ float hi16(uint32_t w) {
+  if constexpr (DT == DT_BF16) return __uint_as_float(w & 0xffff0000u);
+  else return to_f<DT>((uint16_t)(w >> 16));
+}
+
 template <int DT>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
   if constexpr (DT == DT_F16) return (uint32_t)f2h(lo) | ((uint32_t)f2h(hi) << 16);
   else return pack2bf(lo, hi);
 }
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+// One K-step of a 16x16 output tile from the 16 bytes each lane read of the A (weights) and B
+// (pixels) rows.
+template <int DT>
+__device__ __forceinline__ f32x4 mfma_step(const u32x4& a, const u32x4& b, f32x4 c) {
+  if constexpr (DT == DT_BF16) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  } else if constexpr (DT == DT_F16) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  } else {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    return c;
+  }
+}
+
 
 // Runs `...` with the compile-time constant DT bound to the run-time element type `dt`.
 #define DTF_DT_SWITCH(dt, ...)                                                          \

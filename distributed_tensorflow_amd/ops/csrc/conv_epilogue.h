@@ -42,10 +42,12 @@ __device__ __forceinline__ void butterfly16(float (&v)[NV], int fr) {
 
 // m_base: first pixel row of this wave's sub-tile (m0 + wm*WM); co0: see above; mt: M-tile
 // index of the block (selects the statistics replica).
-template <int MR, int NR, bool POINTWISE, int EPI>
+template <int MR, int NR, bool POINTWISE, int EPI, int DT = DT_BF16>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[NR][MR],
                                               const int m_base, const int co0, const int mt,
                                               const int lane) {
+  static_assert(DT == DT_BF16 || DT == DT_F16, "the fused epilogue packs two 16-bit elements per word");
+  typedef typename Elem<DT>::T E;
   constexpr bool BSTATS = EPI == EPI_BSTATS;
   const int fr = lane & 15;
   // ---- epilogue: lane holds 4*NR consecutive channels of pixel (mr, fr) ---------------------
@@ -90,8 +92,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
       opix = (size_t)((int)n * p.OHfull + oh * p.OSH + p.OOH) * p.OWfull + (ow * p.OSW + p.OOW);
     }
     const size_t obase = opix * p.ldc;
-    bf16_t* optr = reinterpret_cast<bf16_t*>(p.out) + obase + co0;
-    const bf16_t* aptr = p.addend ? reinterpret_cast<const bf16_t*>(p.addend) + obase + co0 : nullptr;
+    E* optr = reinterpret_cast<E*>(p.out) + obase + co0;
+    const E* aptr = p.addend ? reinterpret_cast<const E*>(p.addend) + obase + co0 : nullptr;
     const uint8_t* mptr = p.addend_mask ? p.addend_mask + opix * (p.ldc >> 3) + (co0 >> 3) : nullptr;
     if constexpr (CPL >= 8) {
 #pragma unroll
@@ -111,38 +113,38 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
               a.z &= ((b & 16u) ? 0xffffu : 0u) | ((b & 32u) ? 0xffff0000u : 0u);
               a.w &= ((b & 64u) ? 0xffffu : 0u) | ((b & 128u) ? 0xffff0000u : 0u);
             }
-            v0 += __uint_as_float(a.x << 16); v1 += __uint_as_float(a.x & 0xffff0000u);
-            v2 += __uint_as_float(a.y << 16); v3 += __uint_as_float(a.y & 0xffff0000u);
-            v4 += __uint_as_float(a.z << 16); v5 += __uint_as_float(a.z & 0xffff0000u);
-            v6 += __uint_as_float(a.w << 16); v7 += __uint_as_float(a.w & 0xffff0000u);
+            v0 += lo16<DT>(a.x); v1 += hi16<DT>(a.x);
+            v2 += lo16<DT>(a.y); v3 += hi16<DT>(a.y);
+            v4 += lo16<DT>(a.z); v5 += hi16<DT>(a.z);
+            v6 += lo16<DT>(a.w); v7 += hi16<DT>(a.w);
           }
           if (do_relu) {
             v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
             v4 = fmaxf(v4, 0.f); v5 = fmaxf(v5, 0.f); v6 = fmaxf(v6, 0.f); v7 = fmaxf(v7, 0.f);
           }
           u32x4 o;
-          o.x = pack2bf(v0, v1); o.y = pack2bf(v2, v3); o.z = pack2bf(v4, v5); o.w = pack2bf(v6, v7);
+          o.x = pack2<DT>(v0, v1); o.y = pack2<DT>(v2, v3); o.z = pack2<DT>(v4, v5); o.w = pack2<DT>(v6, v7);
           *reinterpret_cast<u32x4*>(optr + h * 8) = o;
           if (EPI != EPI_INFER && p.stats) {
             const uint32_t w[4] = {o.x, o.y, o.z, o.w};
             if constexpr (BSTATS) {                  // sum g, sum g * y  (g = masked output)
-              const u32x4 yq = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.stats_y) + obase + co0 + h * 8);
+              const u32x4 yq = *reinterpret_cast<const u32x4*>(reinterpret_cast<const E*>(p.stats_y) + obase + co0 + h * 8);
               const uint32_t yw[4] = {yq.x, yq.y, yq.z, yq.w};
               const uint32_t sb = p.stats_mask
                   ? p.stats_mask[opix * (p.ldc >> 3) + (co0 >> 3) + h] : 0xffu;
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                const float lo = (sb >> (2 * j)) & 1u ? __uint_as_float(w[j] << 16) : 0.f;
-                const float hi = (sb >> (2 * j + 1)) & 1u ? __uint_as_float(w[j] & 0xffff0000u) : 0.f;
+                const float lo = (sb >> (2 * j)) & 1u ? lo16<DT>(w[j]) : 0.f;
+                const float hi = (sb >> (2 * j + 1)) & 1u ? hi16<DT>(w[j]) : 0.f;
                 st[h * 8 + 2 * j] += lo;
                 st[h * 8 + 2 * j + 1] += hi;
-                st[CPL + h * 8 + 2 * j] += lo * __uint_as_float(yw[j] << 16);
-                st[CPL + h * 8 + 2 * j + 1] += hi * __uint_as_float(yw[j] & 0xffff0000u);
+                st[CPL + h * 8 + 2 * j] += lo * lo16<DT>(yw[j]);
+                st[CPL + h * 8 + 2 * j + 1] += hi * hi16<DT>(yw[j]);
               }
             } else {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+                const float lo = lo16<DT>(w[j]), hi = hi16<DT>(w[j]);
                 st[h * 8 + 2 * j] += lo;
                 st[h * 8 + 2 * j + 1] += hi;
                 st[CPL + h * 8 + 2 * j] += lo * lo;
@@ -156,8 +158,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
           for (int c = 0; c < 8; ++c) {
             if (co0 + h * 8 + c < p.Cout) {
               float x = vv[c];
-              if (aptr) x += bf2f(aptr[h * 8 + c]);
-              optr[h * 8 + c] = f2bf(do_relu ? fmaxf(x, 0.f) : x);
+              if (aptr) x += to_f<DT>(aptr[h * 8 + c]);
+              optr[h * 8 + c] = from_f<DT>(do_relu ? fmaxf(x, 0.f) : x);
             }
           }
         }
@@ -174,36 +176,36 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
             a.x &= ((b & 1u) ? 0xffffu : 0u) | ((b & 2u) ? 0xffff0000u : 0u);
             a.y &= ((b & 4u) ? 0xffffu : 0u) | ((b & 8u) ? 0xffff0000u : 0u);
           }
-          v0 += __uint_as_float(a.x << 16); v1 += __uint_as_float(a.x & 0xffff0000u);
-          v2 += __uint_as_float(a.y << 16); v3 += __uint_as_float(a.y & 0xffff0000u);
+          v0 += lo16<DT>(a.x); v1 += hi16<DT>(a.x);
+          v2 += lo16<DT>(a.y); v3 += hi16<DT>(a.y);
         }
         if (do_relu) {
           v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
         }
         u32x2 o;
-        o.x = pack2bf(v0, v1);
-        o.y = pack2bf(v2, v3);
+        o.x = pack2<DT>(v0, v1);
+        o.y = pack2<DT>(v2, v3);
         *reinterpret_cast<u32x2*>(optr) = o;
         if (EPI != EPI_INFER && p.stats) {
           const uint32_t w[2] = {o.x, o.y};
           if constexpr (BSTATS) {
-            const u32x2 yq = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.stats_y) + obase + co0);
+            const u32x2 yq = *reinterpret_cast<const u32x2*>(reinterpret_cast<const E*>(p.stats_y) + obase + co0);
             const uint32_t yw[2] = {yq.x, yq.y};
             const uint32_t sb = p.stats_mask
                 ? (uint32_t)p.stats_mask[opix * (p.ldc >> 3) + (co0 >> 3)] >> (co0 & 4) : 0xffu;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-              const float lo = (sb >> (2 * j)) & 1u ? __uint_as_float(w[j] << 16) : 0.f;
-              const float hi = (sb >> (2 * j + 1)) & 1u ? __uint_as_float(w[j] & 0xffff0000u) : 0.f;
+              const float lo = (sb >> (2 * j)) & 1u ? lo16<DT>(w[j]) : 0.f;
+              const float hi = (sb >> (2 * j + 1)) & 1u ? hi16<DT>(w[j]) : 0.f;
               st[2 * j] += lo;
               st[2 * j + 1] += hi;
-              st[CPL + 2 * j] += lo * __uint_as_float(yw[j] << 16);
-              st[CPL + 2 * j + 1] += hi * __uint_as_float(yw[j] & 0xffff0000u);
+              st[CPL + 2 * j] += lo * lo16<DT>(yw[j]);
+              st[CPL + 2 * j + 1] += hi * hi16<DT>(yw[j]);
             }
           } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-              const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+              const float lo = lo16<DT>(w[j]), hi = hi16<DT>(w[j]);
               st[2 * j] += lo;
               st[2 * j + 1] += hi;
               st[CPL + 2 * j] += lo * lo;
@@ -217,8 +219,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
         for (int c = 0; c < 4; ++c) {
           if (co0 + c < p.Cout) {
             float x = vv[c];
-            if (aptr) x += bf2f(aptr[c]);
-            optr[c] = f2bf(do_relu ? fmaxf(x, 0.f) : x);
+            if (aptr) x += to_f<DT>(aptr[c]);
+            optr[c] = from_f<DT>(do_relu ? fmaxf(x, 0.f) : x);
           }
         }
       }

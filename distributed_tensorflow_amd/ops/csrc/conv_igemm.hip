@@ -48,27 +48,6 @@ constexpr int bk_of(int dt) { return dt == DT_F32 ? 16 : 32; }
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};
 
 
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-
-// One K-step of a 16x16 output tile from the 16 bytes each lane read of the A (weights) and B
-// (pixels) rows.
-template <int DT>
-__device__ __forceinline__ f32x4 mfma_step(const u32x4& a, const u32x4& b, f32x4 c) {
-  if constexpr (DT == DT_BF16) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  } else if constexpr (DT == DT_F16) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
-                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  } else {
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
-    return c;
-  }
-}
-
 // Addressing modes of the gather (template parameter MODE):
 //   GENERIC    every K-step decodes its k index into (tap i, tap j, channel) per lane - needed
 //              when a 32-wide K-step straddles taps (Ctap not a multiple of 32: CIFAR stages,
@@ -396,9 +375,9 @@ void conv_igemm_kernel(const ConvParams p) {
   }
   }
 
-  if constexpr (DT == DT_BF16)
-    conv_epi::conv_epilogue<MR, NR, POINTWISE, EPI>(p, acc, m0 + wm * WM,
-                                                    n0 + wn * WN + fq * 4 * NR, mt, lane);
+  if constexpr (DT != DT_F32)
+    conv_epi::conv_epilogue<MR, NR, POINTWISE, EPI, DT>(p, acc, m0 + wm * WM,
+                                                        n0 + wn * WN + fq * 4 * NR, mt, lane);
   else
     conv_epi::conv_epilogue_plain<DT, MR, NR, POINTWISE>(p, acc, m0 + wm * WM,
                                                          n0 + wn * WN + fq * 4 * NR, lane);
@@ -424,16 +403,21 @@ void launch_cfg_epi(const ConvParams& p, hipStream_t stream) {
                        dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
 }
 
-// The fused epilogues (BatchNorm statistics, folded inference BatchNorm) exist for bfloat16, the
-// type the engine is tuned for; fp16 / fp32 launches take the plain epilogue (bias, addend) and
-// the planner schedules the separate statistics sweep / BatchNorm launch for them.
+// The fused epilogues (BatchNorm statistics, folded inference BatchNorm) exist for the 16-bit
+// types; fp32 launches take the plain epilogue (bias, addend) and the planner schedules the
+// separate statistics sweep / BatchNorm launch for them.
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N>
+void launch_cfg16(const ConvParams& p, hipStream_t stream) {
+  if (p.scale) launch_cfg_epi<DT, BM, BN, WAVES_M, WAVES_N, EPI_INFER>(p, stream);
+  else if (p.stats_y) launch_cfg_epi<DT, BM, BN, WAVES_M, WAVES_N, EPI_BSTATS>(p, stream);
+  else launch_cfg_epi<DT, BM, BN, WAVES_M, WAVES_N, EPI_PLAIN>(p, stream);
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 void launch_cfg(const ConvParams& p, hipStream_t stream) {
-  if (p.dt == DT_F16) return launch_cfg_epi<DT_F16, BM, BN, WAVES_M, WAVES_N, EPI_PLAIN>(p, stream);
   if (p.dt == DT_F32) return launch_cfg_epi<DT_F32, BM, BN, WAVES_M, WAVES_N, EPI_PLAIN>(p, stream);
-  if (p.scale) launch_cfg_epi<DT_BF16, BM, BN, WAVES_M, WAVES_N, EPI_INFER>(p, stream);
-  else if (p.stats_y) launch_cfg_epi<DT_BF16, BM, BN, WAVES_M, WAVES_N, EPI_BSTATS>(p, stream);
-  else launch_cfg_epi<DT_BF16, BM, BN, WAVES_M, WAVES_N, EPI_PLAIN>(p, stream);
+  if (p.dt == DT_F16) return launch_cfg16<DT_F16, BM, BN, WAVES_M, WAVES_N>(p, stream);
+  launch_cfg16<DT_BF16, BM, BN, WAVES_M, WAVES_N>(p, stream);
 }
 
 // Ring variants (cfg 8..13): bfloat16 training kernels; other element types and the inference
@@ -453,8 +437,8 @@ void validate_conv_params(const ConvParams& p) {
   auto fail = [](const std::string& m) { throw std::invalid_argument("conv_igemm: " + m); };
   if (!p.in || !p.wgt || !p.out) fail("null tensor pointer");
   if (p.dt != DT_BF16 && p.dt != DT_F16 && p.dt != DT_F32) fail("unknown element type");
-  if (p.dt != DT_BF16 && (p.scale || p.stats || p.relu))
-    fail("fused statistics / folded BatchNorm epilogues exist for bfloat16 only");
+  if (p.dt == DT_F32 && (p.scale || p.stats || p.relu))
+    fail("fused statistics / folded BatchNorm epilogues exist for the 16-bit element types only");
   if (p.N <= 0 || p.H <= 0 || p.W <= 0 || p.OH <= 0 || p.OW <= 0) fail("bad spatial size");
   if (p.M != p.N * p.OH * p.OW) fail("M != N*OH*OW");
   if ((int64_t)p.N * p.H * p.W >= (1ll << 31) / 8) fail("input too large for 32-bit pixel index");
@@ -504,7 +488,7 @@ void validate_conv_params(const ConvParams& p) {
 void launch_conv_igemm(const ConvParams& p, int cfg, hipStream_t stream) {
   validate_conv_params(p);
   if (cfg >= 16 && cfg < 32) {
-    if (p.dt == DT_BF16 && launch_conv_pipe(p, cfg, stream)) return;
+    if (p.dt != DT_F32 && launch_conv_pipe(p, cfg, stream)) return;
     cfg = pipe_fallback_cfg(cfg);
   }
   switch (cfg) {

@@ -76,10 +76,12 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int STAGES, int MODE, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int STAGES, int MODE, int EPI,
+          int DT = DT_BF16>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
                              pipe_occ(BM, BN, WAVES_M * WAVES_N, BK, STAGES))
 void conv_pipe_kernel(const ConvParams p) {
+  static_assert(DT == DT_BF16 || DT == DT_F16, "16-bit element types");
   constexpr bool POINTWISE = MODE == POINTWISE_MODE;
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int CPR = BK / 8;                       // 16-byte chunks per tile row
@@ -272,26 +274,26 @@ void conv_pipe_kernel(const ConvParams p) {
     if (read_byte == STAGES * SBYTES) read_byte = 0;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 wf[NR], xf[MR];
+      u32x4 wf[NR], xf[MR];
 #pragma unroll
       for (int nr = 0; nr < NR; ++nr)
-        wf[nr] = *reinterpret_cast<const bf16x8*>(st + (woff[nr] ^ (ks << 6)));
+        wf[nr] = *reinterpret_cast<const u32x4*>(st + (woff[nr] ^ (ks << 6)));
 #pragma unroll
       for (int mr = 0; mr < MR; ++mr)
-        xf[mr] = *reinterpret_cast<const bf16x8*>(st + (xoff[mr] ^ (ks << 6)));
+        xf[mr] = *reinterpret_cast<const u32x4*>(st + (xoff[mr] ^ (ks << 6)));
 #pragma unroll
       for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr)
-          acc[nr][mr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nr], xf[mr], acc[nr][mr], 0, 0, 0);
+          acc[nr][mr] = mfma_step<DT>(wf[nr], xf[mr], acc[nr][mr]);
     }
   }
 
-  conv_epi::conv_epilogue<MR, NR, POINTWISE, EPI>(p, acc, m0 + wm * WM, n0 + wn * WN + fq * 4 * NR,
-                                                  mt, lane);
+  conv_epi::conv_epilogue<MR, NR, POINTWISE, EPI, DT>(p, acc, m0 + wm * WM,
+                                                      n0 + wn * WN + fq * 4 * NR, mt, lane);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int STAGES, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int STAGES, int EPI, int DT>
 bool launch_pipe_epi(const ConvParams& p, hipStream_t stream) {
   const int tilesN = (p.Cout + BN - 1) / BN;
   const int tilesM = (p.M + BM - 1) / BM;
@@ -301,21 +303,32 @@ bool launch_pipe_epi(const ConvParams& p, hipStream_t stream) {
                          p.OH == p.H && p.OW == p.W && p.OHfull == p.OH && p.OWfull == p.OW &&
                          p.Ctap <= p.Cpix;
   if (pointwise)
-    hipLaunchKernelGGL((conv_pipe_kernel<BM, BN, WAVES_M, WAVES_N, BK, STAGES, POINTWISE_MODE, EPI>),
+    hipLaunchKernelGGL((conv_pipe_kernel<BM, BN, WAVES_M, WAVES_N, BK, STAGES, POINTWISE_MODE, EPI, DT>),
                        dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
   else if (p.Ctap % BK == 0)
-    hipLaunchKernelGGL((conv_pipe_kernel<BM, BN, WAVES_M, WAVES_N, BK, STAGES, TAPLOOP, EPI>),
+    hipLaunchKernelGGL((conv_pipe_kernel<BM, BN, WAVES_M, WAVES_N, BK, STAGES, TAPLOOP, EPI, DT>),
                        dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
   else
     return false;
   return true;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int STAGES>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int STAGES, int DT>
+bool launch_pipe_dt(const ConvParams& p, hipStream_t stream) {
+  if (p.scale) return launch_pipe_epi<BM, BN, WAVES_M, WAVES_N, BK, STAGES, EPI_INFER, DT>(p, stream);
+  if (p.stats_y) return launch_pipe_epi<BM, BN, WAVES_M, WAVES_N, BK, STAGES, EPI_BSTATS, DT>(p, stream);
+  return launch_pipe_epi<BM, BN, WAVES_M, WAVES_N, BK, STAGES, EPI_PLAIN, DT>(p, stream);
+}
+
+// F16: the configurations the tile table actually uses are instantiated for IEEE half as well;
+// the others hand half-precision descriptors back to the two-stage kernel.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int STAGES, bool F16 = false>
 bool launch_pipe(const ConvParams& p, hipStream_t stream) {
-  if (p.scale) return launch_pipe_epi<BM, BN, WAVES_M, WAVES_N, BK, STAGES, EPI_INFER>(p, stream);
-  if (p.stats_y) return launch_pipe_epi<BM, BN, WAVES_M, WAVES_N, BK, STAGES, EPI_BSTATS>(p, stream);
-  return launch_pipe_epi<BM, BN, WAVES_M, WAVES_N, BK, STAGES, EPI_PLAIN>(p, stream);
+  if (p.dt == DT_F16) {
+    if constexpr (F16) return launch_pipe_dt<BM, BN, WAVES_M, WAVES_N, BK, STAGES, DT_F16>(p, stream);
+    else return false;
+  }
+  return launch_pipe_dt<BM, BN, WAVES_M, WAVES_N, BK, STAGES, DT_BF16>(p, stream);
 }
 
 }  // namespace
@@ -338,14 +351,14 @@ bool launch_conv_pipe(const ConvParams& p, int cfg, hipStream_t stream) {
   switch (cfg) {
     //                        BM   BN  WM WN  BK  STAGES
     case 16: return launch_pipe<256, 128, 4, 2, 64, 3>(p, stream);   // 144 KiB, 1 block / CU
-    case 17: return launch_pipe<256, 128, 4, 2, 32, 3>(p, stream);   //  72 KiB, 2 blocks / CU
-    case 18: return launch_pipe<128, 128, 2, 2, 64, 2>(p, stream);   //  64 KiB, 2 blocks / CU
+    case 17: return launch_pipe<256, 128, 4, 2, 32, 3, true>(p, stream);   //  72 KiB, 2 blocks / CU
+    case 18: return launch_pipe<128, 128, 2, 2, 64, 2, true>(p, stream);   //  64 KiB, 2 blocks / CU
     case 19: return launch_pipe<128, 128, 2, 2, 64, 3>(p, stream);   //  96 KiB, 1 block / CU
-    case 20: return launch_pipe<128, 128, 2, 2, 32, 3>(p, stream);   //  48 KiB, 3 blocks / CU
-    case 21: return launch_pipe<128, 64, 2, 2, 64, 3>(p, stream);    //  72 KiB, 2 blocks / CU
+    case 20: return launch_pipe<128, 128, 2, 2, 32, 3, true>(p, stream);   //  48 KiB, 3 blocks / CU
+    case 21: return launch_pipe<128, 64, 2, 2, 64, 3, true>(p, stream);    //  72 KiB, 2 blocks / CU
     case 22: return launch_pipe<256, 64, 4, 1, 64, 3>(p, stream);    // 120 KiB, 1 block / CU
-    case 23: return launch_pipe<256, 64, 4, 1, 32, 3>(p, stream);    //  60 KiB, 2 blocks / CU
-    case 24: return launch_pipe<64, 128, 1, 4, 64, 3>(p, stream);    //  72 KiB, 2 blocks / CU
+    case 23: return launch_pipe<256, 64, 4, 1, 32, 3, true>(p, stream);    //  60 KiB, 2 blocks / CU
+    case 24: return launch_pipe<64, 128, 1, 4, 64, 3, true>(p, stream);    //  72 KiB, 2 blocks / CU
     case 25: return launch_pipe<128, 256, 2, 4, 64, 3>(p, stream);   // 144 KiB, 1 block / CU
     case 26: return launch_pipe<256, 128, 4, 2, 32, 4>(p, stream);   //  96 KiB, 1 block / CU
     case 27: return launch_pipe<128, 128, 2, 2, 32, 4>(p, stream);   //  64 KiB, 2 blocks / CU
@@ -353,8 +366,8 @@ bool launch_conv_pipe(const ConvParams& p, int cfg, hipStream_t stream) {
     // (a third fewer bytes staged per multiply-add)
     case 28: return launch_pipe<256, 128, 2, 2, 32, 3>(p, stream);   //  72 KiB, 2 blocks / CU, 4 waves
     case 29: return launch_pipe<256, 256, 2, 4, 32, 3>(p, stream);   //  96 KiB, 1 block / CU, 8 waves
-    case 30: return launch_pipe<256, 256, 4, 4, 32, 3>(p, stream);   //  96 KiB, 1 block / CU, 16 waves
-    case 31: return launch_pipe<128, 256, 2, 4, 32, 3>(p, stream);   //  72 KiB, 2 blocks / CU
+    case 30: return launch_pipe<256, 256, 4, 4, 32, 3, true>(p, stream);   //  96 KiB, 1 block / CU, 16 waves
+    case 31: return launch_pipe<128, 256, 2, 4, 32, 3, true>(p, stream);   //  72 KiB, 2 blocks / CU
     default: throw std::invalid_argument("conv_pipe: unknown tile config");
   }
 }

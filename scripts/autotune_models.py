@@ -3,7 +3,8 @@
 current GPU and writes the cache file used by `ops/autotune.py`.
 
     DTF_AUTOTUNE_OUT=gpurun_out/tuned_gfx950.json python scripts/autotune_models.py \
-        [model:batch ...]          (default: resnet50:256 resnet56:128 resnet50:128 resnet20:128)
+        [model:batch[:dtype] ...]  (default: resnet50:256 resnet56:128 resnet50:128 resnet20:128
+                                    resnet50:256:fp16)
 """
 import os
 import sys
@@ -21,14 +22,15 @@ from distributed_tensorflow_amd.ops import autotune  # noqa: E402
 
 def main():
   jobs = [a for a in sys.argv[1:] if ":" in a] or ["resnet50:256", "resnet56:128",
-                                                   "resnet50:128", "resnet20:128"]
+                                                   "resnet50:128", "resnet20:128",
+                                                   "resnet50:256:fp16"]
   dev = torch.device("cuda", 0)
   for job in jobs:
-    name, batch = job.split(":")
+    name, batch, dtype = (job.split(":") + ["bf16"])[:3]
     t0 = time.time()
     spec = getattr(models, name)()
     store = ParamStore(spec, dev, 0)
-    HipExecutor(spec, store, int(batch), "bf16", use_graph=False)
+    HipExecutor(spec, store, int(batch), dtype, use_graph=False)
     torch.cuda.synchronize()
     print("%s batch %s tuned in %.1fs, cache now %d entries" % (
         name, batch, time.time() - t0, len(autotune._load())), flush=True)

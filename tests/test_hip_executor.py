@@ -423,7 +423,9 @@ def test_dynamic_loss_scale_is_decided_on_the_device():
   def make():
     store = ParamStore(spec, dev, 5)
     store.slot("momentum")
-    return store, HipExecutor(spec, store, N, "fp16", store.make_buckets(1), use_graph=False)
+    # fixed reduction order, so that the two stores can be compared to the last bit
+    return store, HipExecutor(spec, store, N, "fp16", store.make_buckets(1), use_graph=False,
+                              deterministic=True)
 
   sa, ea = make()
   sb, eb = make()
