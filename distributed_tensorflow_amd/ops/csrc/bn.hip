@@ -800,6 +800,120 @@ __global__ __launch_bounds__(TPB) void bn_pool_bwd_kernel(const BnPoolArgs a) {
                                  a.ws + (size_t)blockIdx.x * 2 * C, C);
 }
 
+// k == 3, stride == 2 (the ResNet stem): a thread owns the 2x2 patch of full-resolution elements
+// whose (h + pt, w + pl) are (2a, 2a + 1) x (2b, 2b + 1).  The patch lies in the windows
+// {a, a - 1} x {b, b - 1} and in no other, so four window loads serve four elements (the
+// per-element kernel issues four for each: nine load instructions per 16 bytes of output, here
+// three).  The even row (column) is tap 0 of window a (b) and tap 2 of window a - 1 (b - 1), the
+// odd one is tap 1 of window a (b).
+template <int DT, bool APPLY>
+__global__ __launch_bounds__(TPB) void bn_pool_bwd_quad_kernel(const BnPoolArgs a) {
+  const int C = a.C;
+  const uint32_t cpr = (uint32_t)C >> 3;
+  const uint32_t chunk = threadIdx.x % cpr;
+  float mean[8], invstd[8], sc[8], c1[8], c2[8];
+  load8(a.mean + chunk * 8, mean);
+  load8(a.invstd + chunk * 8, invstd);
+  if constexpr (APPLY) {
+    const float invP = 1.f / ((float)a.N * (float)a.H * (float)a.W);
+    load8(a.gamma + chunk * 8, sc);
+    load8(a.dbeta + chunk * 8, c1);
+    load8(a.dgamma + chunk * 8, c2);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { sc[c] *= invstd[c]; c1[c] *= invP; c2[c] *= invP; }
+  }
+  float part[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) part[i] = 0.f;
+  const uint32_t QH = (uint32_t)(a.H + a.pt + 1) >> 1, QW = (uint32_t)(a.W + a.pl + 1) >> 1;
+  const uint32_t per_row = QW * cpr;
+  for (uint32_t qrow = blockIdx.x; qrow < (uint32_t)a.N * QH; qrow += gridDim.x) {
+    const uint32_t n = qrow / QH;
+    const int qa = (int)(qrow - n * QH);
+    const bool vwr[2] = {qa < a.OH, qa >= 1 && qa - 1 < a.OH};
+    const int ohc[2] = {qa < a.OH ? qa : a.OH - 1, vwr[1] ? qa - 1 : 0};
+    const int h0 = 2 * qa - a.pt;
+    const bool vh[2] = {(unsigned)h0 < (unsigned)a.H, (unsigned)(h0 + 1) < (unsigned)a.H};
+    for (uint32_t j = threadIdx.x; j < per_row; j += TPB) {
+      const int qb = (int)(j / cpr);
+      const bool vwc[2] = {qb < a.OW, qb >= 1 && qb - 1 < a.OW};
+      const int owc[2] = {qb < a.OW ? qb : a.OW - 1, vwc[1] ? qb - 1 : 0};
+      const int w0 = 2 * qb - a.pl;
+      const bool vw[2] = {(unsigned)w0 < (unsigned)a.W, (unsigned)(w0 + 1) < (unsigned)a.W};
+      u32x2 pk[4];
+      Raw8<DT> dq[4], yq[4];
+      size_t off[4];
+      bool ve[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const size_t o = ((size_t)(n * a.OH + ohc[q >> 1]) * a.OW + owc[q & 1]) * C + chunk * 8;
+        pk[q] = *reinterpret_cast<const u32x2*>(a.idx + o);
+        dq[q] = ldraw<DT>(a.dzp, o);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ve[e] = vh[e >> 1] && vw[e & 1];
+        const int h = vh[e >> 1] ? h0 + (e >> 1) : 0, w = vw[e & 1] ? w0 + (e & 1) : 0;
+        off[e] = ((size_t)(n * a.H + h) * a.W + w) * C + chunk * 8;
+        yq[e] = ldraw<DT>(a.y, off[e]);
+      }
+      float d[4][8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unpack8<DT>(dq[q], d[q]);
+        if (!(vwr[q >> 1] && vwc[q & 1])) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) d[q][c] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = e >> 1, cc = e & 1;
+        float g[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) g[c] = 0.f;
+#pragma unroll
+        for (int wr = 0; wr < 2; ++wr) {
+#pragma unroll
+          for (int wc = 0; wc < 2; ++wc) {
+            if ((wr == 1 && r == 1) || (wc == 1 && cc == 1)) continue;   // tap 3 does not exist
+            const int q = wr * 2 + wc;
+            const unsigned tap = (unsigned)((r + 2 * wr) * 3 + (cc + 2 * wc));
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              const unsigned t = ((c < 4 ? pk[q].x : pk[q].y) >> (8 * (c & 3))) & 0xffu;
+              g[c] += t == tap ? d[q][c] : 0.f;
+            }
+          }
+        }
+        float yv[8];
+        unpack8<DT>(yq[e], yv);
+        if constexpr (APPLY) {
+          if (ve[e]) {
+            float o[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              const float xhat = (yv[c] - mean[c]) * invstd[c];
+              o[c] = sc[c] * (g[c] - c1[c] - xhat * c2[c]);
+            }
+            straw<DT>(a.dy, off[e], o);
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const float ge = ve[e] ? g[c] : 0.f;
+            part[c] += ge * ((yv[c] - mean[c]) * invstd[c]);
+            part[8 + c] += ge;
+          }
+        }
+      }
+    }
+  }
+  if constexpr (!APPLY)
+    block_reduce_to_partials<16>(part, (int)cpr, (int)chunk, (int)(threadIdx.x / cpr),
+                                 a.ws + (size_t)blockIdx.x * 2 * C, C);
+}
+
 // Inference: scale = gamma / sqrt(moving_var + eps), shift = beta - moving_mean * scale for every
 // BatchNorm layer of a model in one launch (one block per layer), consumed by the folded
 // convolution epilogue.  Descriptor: five int64 element offsets (gamma and beta in `params`,
@@ -942,13 +1056,20 @@ void launch_bn_pool_bwd(const void* dzp, const uint8_t* idx, const void* y, cons
   a.dgamma = dgamma; a.dbeta = dbeta; a.ws = ws;
   a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.k = k; a.stride = stride;
   a.pt = pt; a.pl = pl;
-  const int rows = N * H;
   // partial rows are 2 * C floats: a narrow layer can use many more blocks than
   // MAX_PARTIAL_BLOCKS within the same workspace (the gathers are latency bound)
   const int cap = (int)(bn_workspace_floats() / (2 * (size_t)C));
+  static const bool quad_ok = [] {
+    const char* e = std::getenv("DTF_BN_POOL_QUAD");
+    return !(e && e[0] == '0');
+  }();
+  const bool quad = quad_ok && k == 3 && stride == 2;
+  const int rows = quad ? N * ((H + pt + 1) / 2) : N * H;
   int G = rows < cap ? rows : cap;
   if (G > 4096) G = 4096;
-  if (stride == 2) {
+  if (quad) {
+    DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_pool_bwd_quad_kernel<DT, false>), dim3(G), dim3(TPB), 0, s, a));
+  } else if (stride == 2) {
     DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_pool_bwd_kernel<DT, false, 2>), dim3(G), dim3(TPB), 0, s, a));
   } else {
     DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_pool_bwd_kernel<DT, false, 0>), dim3(G), dim3(TPB), 0, s, a));
@@ -958,7 +1079,9 @@ void launch_bn_pool_bwd(const void* dzp, const uint8_t* idx, const void* y, cons
               nullptr};
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, b);
   const int ga = rows < 8192 ? rows : 8192;
-  if (stride == 2) {
+  if (quad) {
+    DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_pool_bwd_quad_kernel<DT, true>), dim3(ga), dim3(TPB), 0, s, a));
+  } else if (stride == 2) {
     DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_pool_bwd_kernel<DT, true, 2>), dim3(ga), dim3(TPB), 0, s, a));
   } else {
     DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_pool_bwd_kernel<DT, true, 0>), dim3(ga), dim3(TPB), 0, s, a));
