@@ -40,6 +40,173 @@ __device__ __forceinline__ void butterfly16(float (&v)[NV], int fr) {
 }
 
 
+// Epilogue of a data gradient that also accumulates the backward reductions of the BatchNorm
+// whose output gradient it writes (sum g, sum g*y per channel; g = the stored value gated by the
+// layer's ReLU mask, y = the layer's input).  Three phases:
+//   1. every load of the epilogue (y and its mask, addend and its mask, for all MR pixels) is
+//      issued before anything is stored: written in the store loop they cannot be hoisted over
+//      the stores (the tensors may alias for all the compiler knows), which put 2 * MR memory
+//      latencies back to back in every wave and made this fusion lose against the separate
+//      reduction sweep on large tensors;
+//   2. results are stored pixel by pixel, a lane's channels in consecutive 16-byte stores (splitting
+//      a pixel's bytes over two passes costs ~28 % on the bandwidth-bound layers: partial lines);
+//      the rounded, gated values replace the accumulators;
+//   3. statistics per group of 8 channels from the registers, reduced over the 16 pixel lanes and
+//      added to the replica row.
+template <int MR, int NR, bool POINTWISE, int DT>
+__device__ __forceinline__ void conv_epilogue_bstats(const ConvParams& p, f32x4 (&acc)[NR][MR],
+                                                     const int m_base, const int co0, const int mt,
+                                                     const int lane) {
+  typedef typename Elem<DT>::T E;
+  const int fr = lane & 15;
+  constexpr int CPL = 4 * NR;
+  constexpr int W = CPL >= 8 ? 8 : 4;              // channels per group (one store)
+  constexpr int HV = CPL / W;
+  constexpr int TPG = W / 4;                       // MFMA tiles per group
+  const bool vec_ok = p.ldc % W == 0;
+  size_t opixv[MR];
+  u32x4 ypre[MR][HV], apre[MR][HV];
+  uint32_t sbits[MR][HV], abits[MR][HV];
+#pragma unroll
+  for (int mr = 0; mr < MR; ++mr) {
+    const int m = m_base + mr * 16 + fr;
+    size_t opix = 0;
+    if (m < p.M) {
+      if (POINTWISE) {
+        opix = (size_t)m;
+      } else {
+        const uint32_t t = fd_div((uint32_t)m, p.divOW);
+        const int ow = m - (int)t * p.OW;
+        const uint32_t n = fd_div(t, p.divOH);
+        const int oh = (int)t - (int)n * p.OH;
+        opix = (size_t)((int)n * p.OHfull + oh * p.OSH + p.OOH) * p.OWfull + (ow * p.OSW + p.OOW);
+      }
+    }
+    opixv[mr] = opix;
+#pragma unroll
+    for (int h = 0; h < HV; ++h) {
+      const int cg = co0 + h * W;
+      ypre[mr][h] = u32x4{0u, 0u, 0u, 0u};
+      apre[mr][h] = u32x4{0u, 0u, 0u, 0u};
+      sbits[mr][h] = 0xffu;
+      abits[mr][h] = 0xffu;
+      if (m >= p.M || !vec_ok || cg + W > p.Cout) continue;
+      const size_t e = opix * p.ldc + cg;
+      const size_t mb = opix * (p.ldc >> 3) + (cg >> 3);
+      if constexpr (W == 8) {
+        ypre[mr][h] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const E*>(p.stats_y) + e);
+      } else {
+        const u32x2 q = *reinterpret_cast<const u32x2*>(reinterpret_cast<const E*>(p.stats_y) + e);
+        ypre[mr][h].x = q.x; ypre[mr][h].y = q.y;
+      }
+      // W == 4: the lane's four channels are one nibble of the mask byte
+      if (p.stats_mask) sbits[mr][h] = (uint32_t)p.stats_mask[mb] >> (W == 4 ? (cg & 4) : 0);
+      if (p.addend) {
+        if constexpr (W == 8) {
+          apre[mr][h] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const E*>(p.addend) + e);
+        } else {
+          const u32x2 q = *reinterpret_cast<const u32x2*>(reinterpret_cast<const E*>(p.addend) + e);
+          apre[mr][h].x = q.x; apre[mr][h].y = q.y;
+        }
+        if (p.addend_mask) abits[mr][h] = (uint32_t)p.addend_mask[mb] >> (W == 4 ? (cg & 4) : 0);
+      }
+    }
+  }
+  float bias[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c)
+    bias[c] = (p.bias != nullptr && co0 + c < p.Cout) ? p.bias[co0 + c] : 0.f;
+#pragma unroll
+  for (int mr = 0; mr < MR; ++mr) {
+    if (m_base + mr * 16 + fr >= p.M) continue;
+    const size_t obase = opixv[mr] * p.ldc;
+#pragma unroll
+    for (int h = 0; h < HV; ++h) {
+      const int cg = co0 + h * W;
+      if (cg >= p.Cout) continue;
+      float v[W];
+#pragma unroll
+      for (int t = 0; t < TPG; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[t * 4 + e] = acc[h * TPG + t][mr][e] + bias[h * W + t * 4 + e];
+      E* optr = reinterpret_cast<E*>(p.out) + obase + cg;
+      if (vec_ok && cg + W <= p.Cout) {
+        if (p.addend) {
+          const uint32_t aw[4] = {apre[mr][h].x, apre[mr][h].y, apre[mr][h].z, apre[mr][h].w};
+          const uint32_t bm = abits[mr][h];       // keep only the elements whose mask bit is set
+#pragma unroll
+          for (int j = 0; j < W / 2; ++j) {
+            const uint32_t a = aw[j] & (((bm >> (2 * j)) & 1u ? 0xffffu : 0u) |
+                                        ((bm >> (2 * j + 1)) & 1u ? 0xffff0000u : 0u));
+            v[2 * j] += lo16<DT>(a);
+            v[2 * j + 1] += hi16<DT>(a);
+          }
+        }
+        uint32_t w[W / 2];
+#pragma unroll
+        for (int j = 0; j < W / 2; ++j) w[j] = pack2<DT>(v[2 * j], v[2 * j + 1]);
+        if constexpr (W == 8) {
+          *reinterpret_cast<u32x4*>(optr) = u32x4{w[0], w[1], w[2], w[3]};
+        } else {
+          u32x2 o;
+          o.x = w[0]; o.y = w[1];
+          *reinterpret_cast<u32x2*>(optr) = o;
+        }
+        const uint32_t sb = sbits[mr][h];         // g: the rounded value where the ReLU was open
+#pragma unroll
+        for (int j = 0; j < W / 2; ++j) {
+          acc[h * TPG + (2 * j) / 4][mr][(2 * j) % 4] = (sb >> (2 * j)) & 1u ? lo16<DT>(w[j]) : 0.f;
+          acc[h * TPG + (2 * j + 1) / 4][mr][(2 * j + 1) % 4] = (sb >> (2 * j + 1)) & 1u ? hi16<DT>(w[j]) : 0.f;
+        }
+      } else {                                     // never with statistics (host check); plain store
+        const E* aptr = p.addend ? reinterpret_cast<const E*>(p.addend) + obase + cg : nullptr;
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          if (cg + c < p.Cout) {
+            float x = v[c];
+            if (aptr) x += to_f<DT>(aptr[c]);
+            optr[c] = from_f<DT>(x);
+          }
+          acc[h * TPG + c / 4][mr][c % 4] = 0.f;
+        }
+      }
+    }
+  }
+  if (p.stats == nullptr) return;
+#pragma unroll
+  for (int h = 0; h < HV; ++h) {
+    const int cg = co0 + h * W;
+    float st[2 * W];
+#pragma unroll
+    for (int c = 0; c < 2 * W; ++c) st[c] = 0.f;
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+      if (m_base + mr * 16 + fr >= p.M) continue;
+      const uint32_t yw[4] = {ypre[mr][h].x, ypre[mr][h].y, ypre[mr][h].z, ypre[mr][h].w};
+#pragma unroll
+      for (int j = 0; j < W / 2; ++j) {
+        const float lo = acc[h * TPG + (2 * j) / 4][mr][(2 * j) % 4];
+        const float hi = acc[h * TPG + (2 * j + 1) / 4][mr][(2 * j + 1) % 4];
+        st[2 * j] += lo;
+        st[2 * j + 1] += hi;
+        st[W + 2 * j] += lo * lo16<DT>(yw[j]);
+        st[W + 2 * j + 1] += hi * hi16<DT>(yw[j]);
+      }
+    }
+    constexpr int NV = 2 * W;                      // 16 or 8
+    constexpr int HALVINGS = NV >= 16 ? 4 : 3;
+    butterfly16<NV, NV, 0>(st, fr);                // one total left per lane
+    int base = 0;
+#pragma unroll
+    for (int t = 0; t < HALVINGS; ++t) base += ((fr >> t) & 1) * (NV >> (t + 1));
+    if (HALVINGS == 4 || (fr >> 3) == 0) {
+      float* dst = p.stats + (size_t)(mt % p.stats_replicas) * 2 * p.Cout;
+      const int q = base / W, c = base % W;        // quantity (sum g / sum g*y), channel
+      if (cg + c < p.Cout) atomicAdd(dst + q * p.Cout + cg + c, st[0]);
+    }
+  }
+}
+
 // m_base: first pixel row of this wave's sub-tile (m0 + wm*WM); co0: see above; mt: M-tile
 // index of the block (selects the statistics replica).
 template <int MR, int NR, bool POINTWISE, int EPI, int DT = DT_BF16>
@@ -47,6 +214,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
                                               const int m_base, const int co0, const int mt,
                                               const int lane) {
   static_assert(DT == DT_BF16 || DT == DT_F16, "the fused epilogue packs two 16-bit elements per word");
+  if constexpr (EPI == EPI_BSTATS) {
+    conv_epilogue_bstats<MR, NR, POINTWISE, DT>(p, acc, m_base, co0, mt, lane);
+    return;
+  }
   typedef typename Elem<DT>::T E;
   constexpr bool BSTATS = EPI == EPI_BSTATS;
   const int fr = lane & 15;
