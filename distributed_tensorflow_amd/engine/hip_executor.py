@@ -105,6 +105,12 @@ class HipExecutor:
   # launch latency (ResNet-56 step 3.19 -> 2.97 ms), for large ones it costs more than the
   # sweep it saves (ResNet-50 with every layer fused: 23.37 vs 23.10 ms).
   BWD_STATS_SMALL_BYTES = 8 << 20
+  # A training BatchNorm (+ ReLU) whose only consumer is a unit-stride convolution is folded
+  # into that convolution (it normalises its operand on the way into LDS and writes the
+  # normalised tensor on the side) when the tensor is at most this many bytes: for the
+  # latency-bound layers of the CIFAR ResNets that removes a launch per layer; large layers
+  # keep the sweep (their convolutions fill LDS by DMA, which has no place for arithmetic).
+  BN_PROLOGUE_BYTES = 8 << 20
 
   def __init__(self, spec: ModelSpec, store: ParamStore, batch_size: int, dtype: str = "bf16",
                buckets: Optional[List[Bucket]] = None, use_graph: Optional[bool] = None,
@@ -334,6 +340,40 @@ class HipExecutor:
     self._stats_of_conv = {b.inputs[0]: self.bn_stats.data_ptr() + 4 * self._bn_stats_off[b.name]
                            for b in bn_ops if b.name in self._bn_stats_off}
 
+    # ---- BatchNorm folded into its consumer convolution (see BN_PROLOGUE_BYTES) -------------
+    self._bn_prologue: Dict[str, Op] = {}       # BatchNorm name -> consumer convolution
+    self._prologue_of: Dict[str, Op] = {}       # convolution name -> BatchNorm
+    limit = int(os.environ.get("DTF_BN_PROLOGUE_BYTES", self.BN_PROLOGUE_BYTES))
+    if self.fused_bn_stats and self.dt in (0, 1) and limit > 0:
+      users: Dict[str, List[Op]] = {}
+      for op in spec.ops:
+        for t in op.inputs:
+          users.setdefault(t, []).append(op)
+      for b in bn_ops:
+        # users are listed in execution order: the first one must be the convolution, any later
+        # one (the residual add of the next block) reads the tensor the convolution wrote
+        u = users.get(b.output, [])
+        c = b.attrs["channels"]
+        if (b.name not in self._bn_stats_off or b.name in self._bn_pool
+            or b.name in self._bn_lazy or not u or u[0].kind != "conv"
+            or u[0].inputs[0] != b.output
+            or b.output == spec.logits_name or not 8 <= c <= 128 or c & (c - 1)
+            or acts[b.output].numel() * self.esize > limit):
+          continue
+        if len(b.inputs) > 2 or (len(b.inputs) == 2 and (
+            b.inputs[1] in self._bn_lazy_out
+            or tuple(acts[b.inputs[1]].shape) != tuple(acts[b.output].shape))):
+          continue                     # a residual that is normalised on the fly keeps the sweep
+        g = geoms[u[0].name]
+        pt, _pb, pl, _pr = g.pad
+        if (g.mode == "normal" and g.stride == 1 and g.KH % 2 == 1 and g.KW % 2 == 1
+            and pt == g.KH // 2 and pl == g.KW // 2 and g.OH == g.H and g.OW == g.W
+            and g.Cin == c and g.Cs == c and g.Cout <= 64
+            and g.W <= 64 and 64 % g.W == 0 and (g.H * g.W) % 64 == 0
+            and (64 // g.W + g.KH - 1) * (g.W + g.KW - 1) * c * 2 <= 16384):
+          self._bn_prologue[b.name] = u[0]
+          self._prologue_of[u[0].name] = b
+
     ext = native.ext()
     self.fwd_plan = _TypedPlan(ext.Plan(), self.dt)
     self.eval_plan = _TypedPlan(ext.Plan(), self.dt)
@@ -561,7 +601,32 @@ class HipExecutor:
           d["addend"] = acts[op.inputs[1]].data_ptr()
         self._add(plan, "conv", d, conv.name + "+" + op.name)
         continue
-      if op.kind == "conv":
+      if op.kind == "conv" and training and op.name in self._prologue_of:
+        # the BatchNorm in front of this layer runs in its operand path: it reads the raw output
+        # of the layer before and leaves the normalised tensor (this layer's input, which the
+        # weight gradient reads) and the ReLU mask on the side
+        b = self._prologue_of[op.name]
+        bt = b.attrs
+        C = bt["channels"]
+        g = self.geoms[op.name]
+        mean_p = self.bn_saved.data_ptr() + 4 * self._bn_off[b.name]
+        d = g.fwd(acts[b.inputs[0]].data_ptr(), self._wf_ptr(op.name), acts[op.output].data_ptr(),
+                  stats=self._stats_of_conv.get(op.output), stats_replicas=self.STATS_REPLICAS)
+        d.update(pro_sums=self.bn_stats.data_ptr() + 4 * self._bn_stats_off[b.name],
+                 pro_replicas=self.STATS_REPLICAS, pro_gamma=self._var_ptr(b.name + "/gamma"),
+                 pro_beta=self._var_ptr(b.name + "/beta"),
+                 pro_mm=self._var_ptr(b.name + "/moving_mean"),
+                 pro_mv=self._var_ptr(b.name + "/moving_variance"),
+                 pro_save_mean=mean_p, pro_save_invstd=mean_p + 4 * C, pro_scale=mean_p + 8 * C,
+                 pro_shift=mean_p + 12 * C, pro_z=x.data_ptr(),
+                 pro_mask=self._bn_mask[b.name].data_ptr() if b.name in self._bn_mask else None,
+                 pro_P=x.numel() // C, pro_eps=float(bt["eps"]), pro_momentum=float(bt["momentum"]),
+                 pro_relu=int(bt["relu"]),
+                 pro_res=acts[b.inputs[1]].data_ptr() if len(b.inputs) > 1 else None)
+        if d["cfg"] not in (32, 33, 34, 14):
+          d["cfg"] = 33 if g.Cout <= 16 else 32     # 64-pixel tiles always hold whole image rows
+        self._add(plan, "conv", d, b.name + "+" + op.name)
+      elif op.kind == "conv":
         g = self.geoms[op.name]
         st = self._stats_of_conv.get(op.output) if training else None
         self._add(plan, "conv", g.fwd(x.data_ptr(), self._wf_ptr(op.name), acts[op.output].data_ptr(),
@@ -570,6 +635,8 @@ class HipExecutor:
         g = self.geoms[op.name]
         self._add(plan, "conv", g.fwd(x.data_ptr(), self._wf_ptr(op.name), acts[op.output].data_ptr(),
                                bias=self._var_ptr(op.name + "/bias")), op.name)
+      elif op.kind == "bn" and training and op.name in self._bn_prologue:
+        continue                       # normalised by its consumer convolution, see above
       elif op.kind == "bn":
         C = at["channels"]
         P = x.numel() // C

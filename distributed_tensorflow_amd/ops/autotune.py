@@ -50,7 +50,7 @@ def signature(kind: str, desc: Dict) -> str:
   """Shape key of a descriptor: every integer field, plus which optional tensors are present."""
   parts = [kind]
   for k in sorted(desc):
-    if k in _IGNORED:
+    if k in _IGNORED or (k.startswith("pro_") and k != "pro_relu"):
       continue
     parts.append("%s=%s" % (k, desc[k]))
   for k in ("addend", "addend_mask", "bias", "stats", "scale"):
@@ -61,6 +61,8 @@ def signature(kind: str, desc: Dict) -> str:
         parts.append("+bstats")
         continue
       parts.append("+" + k)
+  if desc.get("pro_sums") is not None:
+    parts.append("+pro")           # BatchNorm of the input folded into the launch
   return "|".join(parts)
 
 
@@ -77,6 +79,12 @@ def lookup(kind: str, desc: Dict) -> Optional[Dict[str, int]]:
 
 def _fwd_candidates(desc: Dict) -> List[int]:
   cout = desc["Cout"]
+  if desc.get("pro_sums") is not None:       # tiles compiled with the BatchNorm prologue
+    if cout <= 16:
+      return [3, 7, 33, 2]
+    if cout <= 32:
+      return [2, 15, 7, 32, 34]
+    return [1, 5, 14, 15, 32, 34]
   if cout <= 16:
     return [3, 2, 8, 12, 7, 33]
   if cout <= 32:
@@ -144,6 +152,9 @@ def _time_op(kind: str, desc: Dict, iters: int = 10, repeats: int = 3) -> float:
   layers (all of them measured 8 - 9 us)."""
   import torch  # pylint: disable=import-outside-toplevel
   from . import native  # pylint: disable=import-outside-toplevel
+  if desc.get("pro_mm") is not None:
+    # a prologue launch updates the moving averages of its BatchNorm: not while timing
+    desc = dict(desc, pro_mm=None, pro_mv=None)
   plan = native.Plan()
   for _ in range(iters):
     plan.add(kind, desc, "", 0)

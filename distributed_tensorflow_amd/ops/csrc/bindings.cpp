@@ -63,6 +63,25 @@ ConvParams conv_from_dict(const py::dict& d) {
   p.stats_replicas = get_or<int>(d, "stats_replicas", 0);
   p.stats_y = ptr<const bf16_t>(d, "stats_y", false);
   p.stats_mask = ptr<const uint8_t>(d, "stats_mask", false);
+  p.pro.sums = ptr<const float>(d, "pro_sums", false);
+  if (p.pro.sums) {
+    p.pro.replicas = get<int>(d, "pro_replicas");
+    p.pro.gamma = ptr<const float>(d, "pro_gamma");
+    p.pro.beta = ptr<const float>(d, "pro_beta");
+    p.pro.moving_mean = ptr<float>(d, "pro_mm", false);
+    p.pro.moving_var = ptr<float>(d, "pro_mv", false);
+    p.pro.save_mean = ptr<float>(d, "pro_save_mean");
+    p.pro.save_invstd = ptr<float>(d, "pro_save_invstd");
+    p.pro.scale = ptr<float>(d, "pro_scale");
+    p.pro.shift = ptr<float>(d, "pro_shift");
+    p.pro.res = ptr<const void>(d, "pro_res", false);
+    p.pro.z = ptr<void>(d, "pro_z", false);
+    p.pro.mask = ptr<uint8_t>(d, "pro_mask", false);
+    p.pro.P = get<int>(d, "pro_P");
+    p.pro.eps = get<float>(d, "pro_eps");
+    p.pro.momentum = get<float>(d, "pro_momentum");
+    p.pro.relu = get_or<int>(d, "pro_relu", 0);
+  }
   p.N = get<int>(d, "N"); p.H = get<int>(d, "H"); p.W = get<int>(d, "W");
   p.Cpix = get<int>(d, "Cpix");
   p.OH = get<int>(d, "OH"); p.OW = get<int>(d, "OW");

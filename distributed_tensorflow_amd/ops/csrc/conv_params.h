@@ -3,6 +3,32 @@
 #pragma once
 #include "common.h"
 
+// Training BatchNorm folded into the *consumer* convolution (small, latency-bound layers): `in`
+// is the raw output y of the producing convolution and the kernel normalises it on its way into
+// LDS, x = relu?(y * scale + shift (+ residual)).  Every block derives scale / shift itself from the sums the
+// producer's epilogue accumulated (`sums`: [replicas][2][C] sum / sum of squares, C = Cpix);
+// block 0 publishes what the backward pass and the moving averages need.  The blocks of the first
+// channel tile also write the normalised values of their own pixels to `z` (the operand of this
+// layer's weight gradient) and the 1-bit ReLU mask.
+struct BnPrologue {
+  const float* sums = nullptr;     // selects the prologue
+  int replicas = 0;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  float* moving_mean = nullptr;    // optional (null: no moving-average update, e.g. while timing)
+  float* moving_var = nullptr;
+  float* save_mean = nullptr;
+  float* save_invstd = nullptr;
+  float* scale = nullptr;          // published scale / shift (same slots the sweep kernels fill)
+  float* shift = nullptr;
+  const void* res = nullptr;       // optional residual added before the ReLU, laid out like `in`
+  void* z = nullptr;               // optional side outputs, laid out like `in`
+  uint8_t* mask = nullptr;         // [pixels][C/8]
+  int P = 0;                       // pixels of `in` (N*H*W): the statistics' sample count
+  float eps = 0.f, momentum = 0.f;
+  int relu = 0;
+};
+
 // Forward / data-gradient gather GEMM; see conv_igemm.hip for the formula.
 struct ConvParams {
   int dt = DT_BF16;                // element type of in / wgt / out / addend (common.h)
@@ -30,6 +56,7 @@ struct ConvParams {
   // launch produces.  Bias-free; an addend is allowed (it is part of the gradient).
   const bf16_t* stats_y = nullptr;
   const uint8_t* stats_mask = nullptr;
+  BnPrologue pro;
   int N = 0, H = 0, W = 0, Cpix = 0;
   int OH = 0, OW = 0, M = 0;       // logical output grid; M = N*OH*OW
   int OHfull = 0, OWfull = 0, ldc = 0;

@@ -496,3 +496,49 @@ def test_deterministic_mode_is_bitwise_reproducible():
     assert torch.equal(u, v)
   c = run(False)
   assert torch.allclose(a[0], c[0], rtol=0, atol=5e-2)        # same training, different rounding
+
+
+def test_batchnorm_prologue_plan_matches_separate_sweeps(monkeypatch):
+  """ResNet-20 (reference `resnet_cifar_model.py:221-241`): BatchNorm layers whose first consumer is
+  a unit-stride convolution run inside that convolution (plain and residual form).  The plan is
+  one launch shorter per such layer and gives the same loss, activations, moving statistics and
+  gradients as separate sweeps.  Both normalise in fp32 and round once, and both accumulate the
+  statistics with float atomics, so two runs of the *same* plan already differ in the last
+  bf16 bit of some activations; the gradient comparison is therefore made against that
+  run-to-run agreement."""
+  from distributed_tensorflow_amd.engine.hip_executor import HipExecutor
+  dev = torch.device("cuda")
+  spec = models.resnet20()
+  N = 32
+  g = torch.Generator().manual_seed(11)
+  x = torch.randn(N, 32, 32, 3, generator=g).to(dev)
+  y = torch.randint(0, 10, (N,), generator=g).to(dev)
+  runs = []
+  for limit in ("0", "0", None):
+    if limit is None:
+      monkeypatch.delenv("DTF_BN_PROLOGUE_BYTES", raising=False)
+    else:
+      monkeypatch.setenv("DTF_BN_PROLOGUE_BYTES", limit)
+    st = ParamStore(spec, dev, 3)
+    ex = HipExecutor(spec, st, N, "bf16", st.make_buckets(1), use_graph=False)
+    loss, _ = ex.train_step(x, y)
+    torch.cuda.synchronize()
+    runs.append((ex, st, loss.item()))
+  (ea, sa, la), (_e2, s2, _l2), (eb, sb, lb) = runs
+  assert not ea._bn_prologue and len(eb._bn_prologue) >= 12
+  assert ea.fwd_plan.size() - eb.fwd_plan.size() == len(eb._bn_prologue)
+  assert any(len(o.inputs) > 1 for o in spec.ops if o.name in eb._bn_prologue)   # residual form too
+  assert abs(la - lb) <= 2e-2 * abs(la)
+  # a fused layer's normalised tensor is the one the sweep writes
+  for name in list(eb._bn_prologue)[:3]:
+    b = next(o for o in spec.ops if o.name == name)
+    assert torch.allclose(ea.acts[b.output].float(), eb.acts[b.output].float(), rtol=3e-2, atol=3e-2)
+
+  def cosine(u, v):
+    u, v = u.grads.double(), v.grads.double()
+    return ((u @ v) / (u.norm() * v.norm())).item()
+
+  floor = cosine(sa, s2)
+  assert cosine(sa, sb) > min(0.99, floor - 0.03), (cosine(sa, sb), floor)
+  # moving statistics were updated by the fused launches as well
+  assert torch.allclose(sa.state, sb.state, rtol=1e-2, atol=1e-3)

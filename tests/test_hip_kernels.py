@@ -860,3 +860,87 @@ def test_batched_weight_gradient_launch(shape, cfg, splits):
     _ref_conv(xs[i].float(), wr, stride, pad).backward(dys[i].float())
     assert (a - wr.grad).abs().max().item() <= 0.01 * wr.grad.abs().max().item() + 1e-2
     assert torch.allclose(a, b, rtol=1e-4, atol=1e-3 * b.abs().max().item())
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 5, 7, 14, 15, 32, 33, 34])
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, K, Cout, relu, residual: the consumer convolutions of the CIFAR ResNet stages
+    (3, 32, 32, 16, 3, 16, 1, 0), (5, 16, 16, 32, 3, 32, 1, 1), (3, 8, 8, 64, 3, 64, 1, 1),
+    (2, 16, 8, 16, 3, 24, 0, 0), (2, 8, 16, 32, 1, 40, 1, 0), (2, 32, 32, 16, 3, 16, 1, 1),
+])
+def test_conv_with_batchnorm_prologue(case, cfg):
+  """Training BatchNorm (+ residual) + ReLU folded into the consumer convolution (reference layer
+  pairs `resnet_cifar_model.py:75-92`, residual form `:94-96`): the launch takes the raw producer
+  output y and the sums its epilogue accumulated, and must give what normalising first (fp32,
+  rounded to bf16 like the separate sweep) and convolving second gives - output, forward
+  statistics of the output, the normalised tensor and ReLU mask it writes on the side, saved and
+  moving statistics.  A tile whose pixel rows are not whole image rows is refused on the host."""
+  from distributed_tensorflow_amd.ops.conv_plan import FWD_CFGS
+  native = _native()
+  N, H, W, Cin, K, Cout, relu, residual = case
+  dev = torch.device("cuda")
+  gen = torch.Generator(device="cpu").manual_seed(hash(case) & 0xffff)
+  pad = same_padding(H, K, 1) + same_padding(W, K, 1)
+  g = ConvGeom(N, H, W, Cin, K, K, Cout, 1, pad)
+  P = N * H * W
+  y = _bf(torch.randn(N, H, W, Cin, generator=gen) * 1.5 + 0.4).to(dev)
+  res = _bf(torch.randn(N, H, W, Cin, generator=gen)).to(dev) if residual else None
+  w = (torch.randn(K, K, Cin, Cout, generator=gen) * (1.0 / math.sqrt(K * K * Cin))).to(dev)
+  gamma = (torch.rand(Cin, generator=gen) + 0.5).to(dev)
+  gamma[::5] *= -1
+  beta = (torch.randn(Cin, generator=gen) * 0.3).to(dev)
+  R = 32
+  # the producer's epilogue: sums spread over replica rows
+  flat = y.float().reshape(P, Cin)
+  rows = torch.arange(P, device=dev) % R
+  sums = torch.zeros(R, 2, Cin, device=dev)
+  sums[:, 0].index_add_(0, rows, flat)
+  sums[:, 1].index_add_(0, rows, flat * flat)
+  mm = torch.full((Cin,), 0.25, device=dev)
+  mv = torch.full((Cin,), 2.0, device=dev)
+  saved = torch.zeros(4 * Cin, device=dev)
+  z = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=dev)
+  mask = torch.zeros(P * Cin // 8, dtype=torch.uint8, device=dev)
+  out = torch.full(g.output_shape, float("nan"), dtype=torch.bfloat16, device=dev)
+  ostats = torch.zeros(R, 2, Cout, device=dev)
+  wf = _pack(native, g, w, "fwd")
+  d = g.fwd(y.data_ptr(), wf.data_ptr(), out.data_ptr(), cfg=cfg,
+            stats=ostats.data_ptr() if Cout % 8 == 0 else None, stats_replicas=R)
+  d.update(pro_sums=sums.data_ptr(), pro_replicas=R, pro_gamma=gamma.data_ptr(),
+           pro_beta=beta.data_ptr(), pro_mm=mm.data_ptr(), pro_mv=mv.data_ptr(),
+           pro_save_mean=saved.data_ptr(), pro_save_invstd=saved.data_ptr() + 4 * Cin,
+           pro_scale=saved.data_ptr() + 8 * Cin, pro_shift=saved.data_ptr() + 12 * Cin,
+           pro_z=z.data_ptr(), pro_mask=mask.data_ptr() if relu else None, pro_P=P, pro_eps=1e-5,
+           pro_momentum=0.9, pro_relu=relu, pro_res=res.data_ptr() if residual else None)
+  BM = FWD_CFGS[cfg][0]
+  fits = BM % W == 0 and (H * W) % BM == 0 and (BM // W + K - 1) * (W + K - 1) * Cin * 2 <= 16384
+  if not fits:
+    with pytest.raises(ValueError):
+      native.run_op("conv", d)
+    return
+  native.run_op("conv", d)
+  torch.cuda.synchronize()
+  mean, var = flat.mean(0), flat.var(0, unbiased=False)
+  invstd = torch.rsqrt(var + 1e-5)
+  zr = (y.float() - mean) * invstd * gamma + beta
+  if residual:
+    zr = zr + res.float()
+  if relu:
+    zr = torch.relu(zr)
+  assert torch.allclose(saved[:Cin], mean, rtol=1e-3, atol=1e-3)
+  assert torch.allclose(saved[Cin:2 * Cin], invstd, rtol=2e-3, atol=1e-3)
+  assert torch.allclose(mm, 0.25 * 0.9 + 0.1 * mean, rtol=1e-3, atol=1e-3)
+  assert torch.allclose(mv, 2.0 * 0.9 + 0.1 * var * P / (P - 1), rtol=2e-3, atol=1e-3)
+  assert torch.isfinite(z.float()).all()
+  assert torch.allclose(z.float(), zr, rtol=2e-2, atol=3e-2)
+  if relu:
+    bits = ((mask.view(P, Cin // 8, 1).to(torch.int32) >> torch.arange(8, device=dev)) & 1).bool()
+    assert torch.equal(bits.view(N, H, W, Cin), z > 0)
+  # the convolution consumes exactly the tensor it wrote
+  ref = _ref_conv(z.float(), _bf(w).float(), 1, pad)
+  err = (out.float()[..., :Cout] - ref).abs().max().item()
+  assert err <= 0.02 * ref.abs().max().item() + 1e-2, err
+  if Cout % 8 == 0:
+    o = out.float().reshape(P, -1)[:, :Cout]
+    assert torch.allclose(ostats[:, 0].sum(0), o.sum(0), rtol=1e-2, atol=0.5)
+    assert torch.allclose(ostats[:, 1].sum(0), (o * o).sum(0), rtol=1e-2, atol=0.5)
