@@ -370,7 +370,8 @@ class HipExecutor:
             and pt == g.KH // 2 and pl == g.KW // 2 and g.OH == g.H and g.OW == g.W
             and g.Cin == c and g.Cs == c and g.Cout <= 64
             and g.W <= 64 and 64 % g.W == 0 and (g.H * g.W) % 64 == 0
-            and (64 // g.W + g.KH - 1) * (g.W + g.KW - 1) * c * 2 <= 16384):
+            and (64 // g.W + g.KH - 1) * (g.W + g.KW - 1) * c * 2 <= 16384
+            and -(-g.KH * g.KW * c // 32) * min(32, g.Cout) * 64 <= 40960):
           self._bn_prologue[b.name] = u[0]
           self._prologue_of[u[0].name] = b
 
@@ -623,8 +624,7 @@ class HipExecutor:
                  pro_P=x.numel() // C, pro_eps=float(bt["eps"]), pro_momentum=float(bt["momentum"]),
                  pro_relu=int(bt["relu"]),
                  pro_res=acts[b.inputs[1]].data_ptr() if len(b.inputs) > 1 else None)
-        if d["cfg"] not in (32, 33, 34, 14):
-          d["cfg"] = 33 if g.Cout <= 16 else 32     # 64-pixel tiles always hold whole image rows
+        d["cfg"] = 42 if g.Cout <= 16 else 45       # 64-pixel tiles always hold whole image rows
         self._add(plan, "conv", d, b.name + "+" + op.name)
       elif op.kind == "conv":
         g = self.geoms[op.name]

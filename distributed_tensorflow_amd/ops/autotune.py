@@ -79,20 +79,23 @@ def lookup(kind: str, desc: Dict) -> Optional[Dict[str, int]]:
 
 def _fwd_candidates(desc: Dict) -> List[int]:
   cout = desc["Cout"]
-  if desc.get("pro_sums") is not None:       # tiles compiled with the BatchNorm prologue
-    if cout <= 16:
-      return [3, 7, 33, 2]
-    if cout <= 32:
-      return [2, 15, 7, 32, 34]
-    return [1, 5, 14, 15, 32, 34]
+  # 40..47: the one-round-trip kernel for small layers (conv_halo.hip); a descriptor it cannot
+  # serve falls back to the two-buffer tile of the same footprint, or is refused (ValueError,
+  # skipped by the tuner) when it carries a BatchNorm prologue
+  halo = [40, 41, 42] if cout <= 16 else [43, 44, 45, 46] if cout <= 32 else [45, 46, 47]
+  if desc.get("pro_sums") is not None:
+    return halo
+  small = desc.get("N", 0) * desc.get("OH", 0) * desc.get("OW", 0) * desc.get("Cpix", 0) <= (8 << 20)
+  if not small:
+    halo = []
   if cout <= 16:
-    return [3, 2, 8, 12, 7, 33]
+    return [3, 2, 8, 12, 7, 33] + halo
   if cout <= 32:
-    return [2, 1, 9, 13, 15, 7, 32, 34]
+    return [2, 1, 9, 13, 15, 7, 32, 34] + halo
   # 16..: the multi-stage pipeline of conv_pipe.hip (descriptors it cannot serve fall back to
   # the two-stage tile of the same footprint, so listing them is always safe)
   if cout <= 64:
-    return [1, 5, 0, 21, 22, 23, 20, 10, 11, 14, 15, 32, 34]
+    return [1, 5, 0, 21, 22, 23, 20, 10, 11, 14, 15, 32, 34] + halo
   wide = [29, 30, 31] if cout >= 256 else []       # 256 output channels per block
   return [0, 6, 4, 5, 1, 16, 17, 18, 19, 20, 21, 24, 25, 26, 27, 28] + wide
 

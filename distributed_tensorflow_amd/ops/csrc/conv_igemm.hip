@@ -84,20 +84,10 @@ using conv_epi::EPI_INFER;
 // the short reductions of the CIFAR ResNets (K = 144 .. 576 in 32-wide steps whose channels
 // straddle taps): with two buffers such a block is a chain of 5 - 18 dependent DMA round trips
 // and nothing else, with a ring it is two or three.
-//
-// PRO: training BatchNorm of the *input* folded into this launch (BnPrologue in conv_params.h;
-// generic weight addressing, two buffers).  The block normalises its pixel rows and their border
-// once into a halo tile in LDS and every tap reads its operand there; only the weight tile still
-// streams per K-step.  This is for the small layers of the CIFAR ResNets, whose kernels are
-// chains of a few dependent memory round trips: one launch instead of two saves about 2 us per
-// layer there (ResNet-56 forward: 122 -> 73 launches), while the convolutions of large layers
-// fill LDS by DMA and have no register stage to do arithmetic in.
 template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int EPI = EPI_PLAIN,
-          int STAGES = 2, bool PRO = false>
+          int STAGES = 2>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 2 ? 4 : 2)
 void conv_igemm_kernel(const ConvParams p) {
-  static_assert(!PRO || (MODE == GENERIC && STAGES == 2 && DT != DT_F32),
-                "the BatchNorm prologue is built on the generic two-buffer gather, 16-bit types");
   typedef typename Elem<DT>::T T;
   constexpr int EPC = 16 / (int)sizeof(T);          // elements per 16-byte chunk: 8 or 4
   constexpr int BK = 64 / (int)sizeof(T);           // elements per K-step (one 64-byte row)
@@ -266,141 +256,6 @@ void conv_igemm_kernel(const ConvParams p) {
     }
   };
 
-  // ---- PRO: only the weight tile streams per K-step ------------------------------------------
-  auto issue_w = [&](int buf) {      // the weight half of issue_tile
-    uint8_t* ws = smem + buf * (XBYTES + WBYTES) + XBYTES;
-    const bool kvalw = kkw < p.Ktotal;
-    const int wk = p.wk0 + tiw * p.wsi + tjw * p.wsj + kcw;
-#pragma unroll
-    for (int r = 0; r < WV; ++r) {
-      if (RPP * r + wave * 16 < BN) {
-        const int co = n0 + lrow + RPP * r;
-        const bool ok = kvalw && co < p.Cout;
-        const T* src = ok ? gw + ((size_t)co * p.ldw + wk) : zero_page;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ws + r * (RPP * 64) + wave * 1024), 16, 0, 0);
-      }
-    }
-  };
-
-  // ---- BatchNorm prologue ----------------------------------------------------------------------
-  // The block's pixels are BM / W whole rows of one image (host check).  Those rows plus the
-  // border the taps reach go through registers once - y * scale + shift (+ residual), ReLU - into
-  // a halo tile [rows + TI - 1][W + TJ - 1][C] in LDS, zeros outside the image; every tap of the
-  // K loop reads its operand there.  The channel tile 0 blocks also store their own pixels'
-  // normalised values (the input of this layer's weight gradient, a later layer's residual)
-  // and ReLU bits.  Three global round trips are in flight together: the first weight tile
-  // (DMA), the raw pixels of the halo tile (registers), the producer's replica sums.
-  constexpr int HALO_BYTES = PRO ? 16384 : 16;
-  __shared__ __attribute__((aligned(16))) uint8_t halo[HALO_BYTES];
-  __shared__ __attribute__((aligned(16))) float pro_sc[PRO ? 128 : 4];
-  __shared__ __attribute__((aligned(16))) float pro_sh[PRO ? 128 : 4];
-  const int HW = p.W + p.TJ - 1;       // halo row, pixels
-  const int KT = (p.Ktotal + BK - 1) / BK;
-  if constexpr (PRO) {
-    constexpr int NT = 64 * NW;
-    constexpr int HCH = HALO_BYTES / 16 / NT;      // halo chunks per thread at most
-    if (KT > 0) {
-      issue_w(0);
-      advance_k();
-    }
-    const int C = p.Cpix, cpr = C >> 3, cols = 2 * C;
-    const int img = p.H * p.W;
-    const int n_img = m0 / img;
-    const int r0 = (m0 - n_img * img) / p.W;
-    const int RB = BM / p.W;
-    const int total = (RB + p.TI - 1) * HW * cpr;
-    const T* gres = reinterpret_cast<const T*>(p.pro.res);
-    u32x4 yv[HCH], rv[HCH];
-    size_t hsrc[HCH];
-    bool hok[HCH], hown[HCH];
-#pragma unroll
-    for (int u = 0; u < HCH; ++u) {
-      const int idx = tid + u * NT;
-      const int ch = idx % cpr, px = idx / cpr;
-      const int wc = px % HW, hr = px / HW;
-      const int hi = r0 + hr + p.dh0, wi = wc + p.dw0;
-      hok[u] = idx < total && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      hown[u] = (unsigned)(hr + p.dh0) < (unsigned)RB;       // one of the block's own rows
-      hsrc[u] = hok[u] ? ((size_t)(n_img * p.H + hi) * p.W + wi) * C + ch * 8 : 0;
-      yv[u] = hok[u] ? *reinterpret_cast<const u32x4*>(gin + hsrc[u]) : u32x4{0u, 0u, 0u, 0u};
-      rv[u] = (hok[u] && gres != nullptr) ? *reinterpret_cast<const u32x4*>(gres + hsrc[u])
-                                          : u32x4{0u, 0u, 0u, 0u};
-    }
-    // column sums of [replicas][2*C] (2*C <= 256 <= threads, checked on the host): thread
-    // (row lane rl, column col) adds every RL-th replica row, one LDS round joins the row lanes
-    const int RL = NT / cols;
-    const int col = tid % cols, rl = tid / cols;
-    float* part = reinterpret_cast<float*>(halo);           // the halo tile is filled afterwards
-    if (rl < RL) {
-      float sum = 0.f;
-      for (int g = rl; g < p.pro.replicas; g += RL) sum += p.pro.sums[(size_t)g * cols + col];
-      part[rl * cols + col] = sum;
-    }
-    __syncthreads();
-    if (tid < C) {
-      float s1 = 0.f, s2 = 0.f;
-      for (int r = 0; r < RL; ++r) { s1 += part[r * cols + tid]; s2 += part[r * cols + C + tid]; }
-      const float invP = 1.f / (float)p.pro.P;
-      const float mean = s1 * invP;
-      const float var = fmaxf(s2 * invP - mean * mean, 0.f);
-      const float invstd = rsqrtf(var + p.pro.eps);
-      const float k = p.pro.gamma[tid] * invstd;
-      const float sh = p.pro.beta[tid] - mean * k;
-      pro_sc[tid] = k;
-      pro_sh[tid] = sh;
-      if (bid == 0) {                  // one block publishes what backward / evaluation need
-        p.pro.scale[tid] = k;
-        p.pro.shift[tid] = sh;
-        p.pro.save_mean[tid] = mean;
-        p.pro.save_invstd[tid] = invstd;
-        if (p.pro.moving_mean != nullptr) {
-          const float unbiased = p.pro.P > 1 ? var * ((float)p.pro.P / (float)(p.pro.P - 1)) : var;
-          p.pro.moving_mean[tid] = p.pro.moving_mean[tid] * p.pro.momentum + mean * (1.f - p.pro.momentum);
-          p.pro.moving_var[tid] = p.pro.moving_var[tid] * p.pro.momentum + unbiased * (1.f - p.pro.momentum);
-        }
-      }
-    }
-    __syncthreads();                   // scale / shift visible; `part` has been read
-    const bool side = p.pro.z != nullptr && nt == 0;
-#pragma unroll
-    for (int u = 0; u < HCH; ++u) {
-      const int idx = tid + u * NT;
-      if (idx >= total) continue;
-      u32x4 ov = u32x4{0u, 0u, 0u, 0u};
-      if (hok[u]) {
-        const int ch = idx % cpr;
-        const f32x4 sc0 = *reinterpret_cast<const f32x4*>(pro_sc + ch * 8);
-        const f32x4 sc1 = *reinterpret_cast<const f32x4*>(pro_sc + ch * 8 + 4);
-        const f32x4 sh0 = *reinterpret_cast<const f32x4*>(pro_sh + ch * 8);
-        const f32x4 sh1 = *reinterpret_cast<const f32x4*>(pro_sh + ch * 8 + 4);
-        const float sc[8] = {sc0[0], sc0[1], sc0[2], sc0[3], sc1[0], sc1[1], sc1[2], sc1[3]};
-        const float sh[8] = {sh0[0], sh0[1], sh0[2], sh0[3], sh1[0], sh1[1], sh1[2], sh1[3]};
-        const uint32_t w[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
-        const uint32_t rw[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
-        uint32_t o[4];
-        uint32_t bits = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float lo = lo16<DT>(w[j]) * sc[2 * j] + sh[2 * j] + lo16<DT>(rw[j]);
-          float hi2 = hi16<DT>(w[j]) * sc[2 * j + 1] + sh[2 * j + 1] + hi16<DT>(rw[j]);
-          if (p.pro.relu) {
-            bits |= (lo > 0.f ? 1u : 0u) << (2 * j);
-            bits |= (hi2 > 0.f ? 1u : 0u) << (2 * j + 1);
-            lo = fmaxf(lo, 0.f);
-            hi2 = fmaxf(hi2, 0.f);
-          }
-          o[j] = pack2<DT>(lo, hi2);
-        }
-        ov = u32x4{o[0], o[1], o[2], o[3]};
-        if (side && hown[u]) {           // hok: the column is inside the image as well
-          *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.pro.z) + hsrc[u]) = ov;
-          if (p.pro.mask != nullptr) p.pro.mask[hsrc[u] >> 3] = (uint8_t)bits;
-        }
-      }
-      *reinterpret_cast<u32x4*>(halo + (size_t)idx * 16) = ov;
-    }
-  }
-
   // ---- fragment addresses (loop invariant) -------------------------------------------
   const int fr = lane & 15, fq = lane >> 4;
   int xoff[MR], woff[NR];
@@ -416,21 +271,13 @@ void conv_igemm_kernel(const ConvParams p) {
     woff[nr] = row * 64 + ((fq ^ ((-(row / (4 * NR))) & 3)) << 4);
   }
 
-  // PRO: byte offset of the lane's pixel (mr, fr) in the halo tile, before the tap offset
-  int hoff[MR];
-  const int cshift = __ffs(p.Cpix) - 1;            // Cpix is a power of two in PRO launches
-#pragma unroll
-  for (int mr = 0; mr < MR; ++mr) {
-    const int prow = wm * WM + mr * 16 + fr;
-    hoff[mr] = PRO ? (((prow / p.W) * HW + (prow % p.W)) << (cshift + 1)) : 0;
-  }
-
   f32x4 acc[NR][MR];
 #pragma unroll
   for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) acc[nr][mr] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const int KT = (p.Ktotal + BK - 1) / BK;
   if constexpr (STAGES > 2) {
     // ---- ring of STAGES buffers ----------------------------------------------------------
     // vector-memory operations this wave issues per stage: its pixel pieces plus the weight
@@ -490,9 +337,7 @@ void conv_igemm_kernel(const ConvParams p) {
           acc[nr][mr] = mfma_step<DT>(wf[nr], xf[mr], acc[nr][mr]);
     }
   } else {
-  if constexpr (PRO) {
-    // stage 0 of the weights was issued by the prologue
-  } else if constexpr (MODE == TAPLOOP) {
+  if constexpr (MODE == TAPLOOP) {
     setup_tap();
     if (KT > 0) issue_tile_tap(0);
   } else if (KT > 0) {
@@ -506,10 +351,7 @@ void conv_igemm_kernel(const ConvParams p) {
     const int buf = kt & 1;
     const bool more = kt + 1 < KT;
     if (more) {                                    // next tile streams into the other buffer
-      if constexpr (PRO) {                         // while this one is multiplied
-        issue_w(buf ^ 1);
-        advance_k();
-      } else if constexpr (MODE == TAPLOOP) {
+      if constexpr (MODE == TAPLOOP) {             // while this one is multiplied
         issue_tile_tap(buf ^ 1);
       } else {
         issue_tile(buf ^ 1);
@@ -521,21 +363,8 @@ void conv_igemm_kernel(const ConvParams p) {
     u32x4 wf[NR], xf[MR];
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) wf[nr] = *reinterpret_cast<const u32x4*>(ws + woff[nr]);
-    if constexpr (PRO) {
-      // this lane's 8 K values of the step: tap (ti, tj), channels chn .. chn + 7.  Past the last
-      // tap the weights are zeros; the pixel operand only has to be finite: the last tap again
-      const int kk = kt * BK + fq * EPC;
-      int tap = kk >> cshift;
-      const int chn = kk - (tap << cshift);
-      tap = tap < p.TI * p.TJ ? tap : p.TI * p.TJ - 1;
-      const int ti = tap / p.TJ, tj = tap - ti * p.TJ;
-      const int toff = (((ti * HW + tj) << cshift) + chn) * 2;
 #pragma unroll
-      for (int mr = 0; mr < MR; ++mr) xf[mr] = *reinterpret_cast<const u32x4*>(halo + hoff[mr] + toff);
-    } else {
-#pragma unroll
-      for (int mr = 0; mr < MR; ++mr) xf[mr] = *reinterpret_cast<const u32x4*>(xs + xoff[mr]);
-    }
+    for (int mr = 0; mr < MR; ++mr) xf[mr] = *reinterpret_cast<const u32x4*>(xs + xoff[mr]);
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
@@ -591,24 +420,6 @@ void launch_cfg(const ConvParams& p, hipStream_t stream) {
   launch_cfg16<DT_BF16, BM, BN, WAVES_M, WAVES_N>(p, stream);
 }
 
-// BatchNorm prologue (p.pro.sums): generic gather, plain epilogue (with forward statistics).
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-void launch_pro(const ConvParams& p, hipStream_t stream) {
-  // a block's BM pixels must be whole rows of one image, and their halo tile must fit
-  if (BM % p.W || (p.H * p.W) % BM ||
-      (BM / p.W + p.TI - 1) * (p.W + p.TJ - 1) * p.Cpix * 2 > 16384)
-    throw std::invalid_argument("conv_igemm: this tile cannot hold the layer's rows for the BatchNorm prologue");
-  const int tilesN = (p.Cout + BN - 1) / BN;
-  const int tilesM = (p.M + BM - 1) / BM;
-  const int grid = ((tilesM + 7) / 8) * 8 * tilesN;
-  if (p.dt == DT_F16)
-    hipLaunchKernelGGL((conv_igemm_kernel<DT_F16, BM, BN, WAVES_M, WAVES_N, GENERIC, EPI_PLAIN, 2, true>),
-                       dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
-  else
-    hipLaunchKernelGGL((conv_igemm_kernel<DT_BF16, BM, BN, WAVES_M, WAVES_N, GENERIC, EPI_PLAIN, 2, true>),
-                       dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
-}
-
 // Ring variants (cfg 8..13): bfloat16 training kernels; other element types and the inference
 // epilogue take the two-stage kernel of the same tile.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
@@ -655,19 +466,16 @@ void validate_conv_params(const ConvParams& p) {
   }
   if (p.pro.sums) {
     const int C = p.Cpix;
-    if (p.dt == DT_F32) fail("the BatchNorm prologue exists for the 16-bit element types");
     if (p.scale || p.stats_y || p.addend || p.bias) fail("the BatchNorm prologue goes with the plain training epilogue");
-    if (p.Ctap != C || C % 8 || C > 128 || (C & (C - 1))) fail("BatchNorm prologue: taps must be whole pixels of 8..128 (power of two) channels");
+    if (C > 128) fail("BatchNorm prologue: at most 128 input channels");
     if (p.pro.replicas <= 0 || p.pro.P != p.N * p.H * p.W) fail("BatchNorm prologue: bad replica count / sample count");
     if (!p.pro.gamma || !p.pro.beta || !p.pro.save_mean || !p.pro.save_invstd || !p.pro.scale || !p.pro.shift)
       fail("BatchNorm prologue: missing parameter / output vector");
     if ((p.pro.moving_mean == nullptr) != (p.pro.moving_var == nullptr)) fail("BatchNorm prologue: moving mean and variance come together");
     if (p.pro.mask && !p.pro.z) fail("BatchNorm prologue: the mask is written along with z");
-    // unit-stride forward convolution over the same grid, taps centred on the output pixel
-    if (p.ISH != 1 || p.ISW != 1 || p.dhs != 1 || p.dws != 1 || p.OH != p.H || p.OW != p.W ||
-        p.OSH != 1 || p.OSW != 1 || p.OOH != 0 || p.OOW != 0 || p.OHfull != p.OH || p.OWfull != p.OW ||
-        p.dh0 > 0 || -p.dh0 >= p.TI || p.dw0 > 0 || -p.dw0 >= p.TJ)
-      fail("BatchNorm prologue: needs a unit-stride convolution whose taps cover the output pixel");
+    // the block's own rows must lie inside its halo tile: forward taps that cover the output pixel
+    if (p.dhs != 1 || p.dws != 1 || p.dh0 > 0 || -p.dh0 >= p.TI || p.dw0 > 0 || -p.dw0 >= p.TJ)
+      fail("BatchNorm prologue: needs forward taps that cover the output pixel");
   }
   if ((p.stats_y || p.stats_mask) && !p.stats) fail("stats_y / stats_mask without a stats buffer");
   if (p.stats_mask && !p.stats_y) fail("stats_mask belongs to the backward statistics (stats_y)");
@@ -687,26 +495,19 @@ void validate_conv_params(const ConvParams& p) {
   }
 }
 
-// cfg 0..15 and 32..: the kernel of this file; cfg 16..31: the multi-stage pipeline of
+// cfg 0..15 and 32..39: the kernel of this file; cfg 16..31: the multi-stage pipeline of
 // conv_pipe.hip, which hands descriptors that need the generic gather back to the tile of
-// this file with the same footprint.
+// this file with the same footprint; cfg 40..47: the one-round-trip kernel for small layers of
+// conv_halo.hip (same fallback rule; the only one that runs a BatchNorm prologue).
 void launch_conv_igemm(const ConvParams& p, int cfg, hipStream_t stream) {
   validate_conv_params(p);
-  if (p.pro.sums) {
-    switch (cfg) {
-      case 1: launch_pro<256, 64, 4, 1>(p, stream); break;
-      case 2: launch_pro<256, 32, 4, 1>(p, stream); break;
-      case 3: launch_pro<256, 16, 4, 1>(p, stream); break;
-      case 5: launch_pro<128, 64, 2, 2>(p, stream); break;
-      case 7: launch_pro<128, 16, 4, 1>(p, stream); break;
-      case 14: launch_pro<64, 64, 2, 2>(p, stream); break;
-      case 15: launch_pro<128, 32, 4, 1>(p, stream); break;
-      case 32: launch_pro<64, 32, 4, 1>(p, stream); break;
-      case 33: launch_pro<64, 16, 4, 1>(p, stream); break;
-      case 34: launch_pro<64, 32, 2, 2>(p, stream); break;
-      default: throw std::invalid_argument("conv_igemm: this tile has no BatchNorm-prologue variant");
-    }
-    return;
+  if (cfg >= 40 && cfg < 48) {
+    if (launch_conv_halo(p, cfg, stream)) return;
+    if (p.pro.sums)
+      throw std::invalid_argument("conv: this tile cannot run the layer with a BatchNorm prologue");
+    cfg = halo_fallback_cfg(cfg);
+  } else if (p.pro.sums) {
+    throw std::invalid_argument("conv: a BatchNorm prologue needs a tile configuration of conv_halo.hip (40..47)");
   }
   if (cfg >= 16 && cfg < 32) {
     if (p.dt != DT_F32 && launch_conv_pipe(p, cfg, stream)) return;

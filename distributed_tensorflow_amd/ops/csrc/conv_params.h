@@ -101,4 +101,7 @@ void launch_conv_igemm(const ConvParams& p, int cfg, hipStream_t stream);
 // conv_pipe.hip: false when the descriptor needs the generic gather of conv_igemm.hip
 bool launch_conv_pipe(const ConvParams& p, int cfg, hipStream_t stream);
 int pipe_fallback_cfg(int cfg);
+// conv_halo.hip: false when the tile cannot serve the descriptor
+bool launch_conv_halo(const ConvParams& p, int cfg, hipStream_t stream);
+int halo_fallback_cfg(int cfg);
 void launch_conv_wgrad(const WgradParams& p, int cfg, hipStream_t stream);

@@ -862,7 +862,22 @@ def test_batched_weight_gradient_launch(shape, cfg, splits):
     assert torch.allclose(a, b, rtol=1e-4, atol=1e-3 * b.abs().max().item())
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 5, 7, 14, 15, 32, 33, 34])
+@pytest.mark.parametrize("cfg", list(range(40, 48)))
+@pytest.mark.parametrize("case", [
+    # unit-stride layers of the CIFAR ResNet stages through the one-round-trip kernel
+    # (conv_halo.hip: halo tile + resident weights); shapes a tile cannot hold (pixel rows that are
+    # not whole image rows, weight slab too large) fall back to the two-buffer tile of the same
+    # footprint, so every combination must give the right numbers
+    (3, 32, 32, 16, 3, 16, 1), (5, 16, 16, 32, 3, 32, 1), (3, 8, 8, 64, 3, 64, 1),
+    (2, 16, 8, 16, 3, 24, 1), (2, 8, 16, 32, 1, 40, 1), (3, 17, 17, 16, 3, 32, 2),
+    (2, 15, 13, 24, 3, 40, 1),
+])
+def test_conv_halo_cfgs(case, cfg):
+  """Forward, data gradient (taps walked backwards over the halo tile) and accumulate mode."""
+  _check_conv_cfg(case, cfg)
+
+
+@pytest.mark.parametrize("cfg", list(range(40, 48)))
 @pytest.mark.parametrize("case", [
     # N, H, W, Cin, K, Cout, relu, residual: the consumer convolutions of the CIFAR ResNet stages
     (3, 32, 32, 16, 3, 16, 1, 0), (5, 16, 16, 32, 3, 32, 1, 1), (3, 8, 8, 64, 3, 64, 1, 1),
@@ -912,8 +927,9 @@ def test_conv_with_batchnorm_prologue(case, cfg):
            pro_scale=saved.data_ptr() + 8 * Cin, pro_shift=saved.data_ptr() + 12 * Cin,
            pro_z=z.data_ptr(), pro_mask=mask.data_ptr() if relu else None, pro_P=P, pro_eps=1e-5,
            pro_momentum=0.9, pro_relu=relu, pro_res=res.data_ptr() if residual else None)
-  BM = FWD_CFGS[cfg][0]
-  fits = BM % W == 0 and (H * W) % BM == 0 and (BM // W + K - 1) * (W + K - 1) * Cin * 2 <= 16384
+  BM, BN = FWD_CFGS[cfg]
+  fits = BM % W == 0 and (H * W) % BM == 0 and (BM // W + K - 1) * (W + K - 1) * Cin * 2 <= 16384 \
+      and -(-K * K * Cin // 32) * BN * 64 <= 40960
   if not fits:
     with pytest.raises(ValueError):
       native.run_op("conv", d)
