@@ -94,28 +94,63 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(
   }
 }
 
+// One block per sample.  The 256 threads are (pixel lane, 8-channel chunk): a narrow tensor
+// (CIFAR: 64 channels = 8 chunks) spreads its pixels over 32 lanes that meet in LDS - with one
+// thread per chunk walking all pixels the launch was four blocks of 64 dependent loads (22 us).
 template <int DT>
 __global__ __launch_bounds__(256) void global_mean_fwd_kernel(const void* __restrict__ x,
                                                               void* __restrict__ out, int N,
                                                               int HW, int C) {
+  __shared__ float red[256 * 8];
   const int cpr = C >> 3;
-  const int total = N * cpr;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int chunk = i % cpr, n = i / cpr;
-  float s[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) s[c] = 0.f;
-  for (int p = 0; p < HW; ++p) {
-    float f[8];
-    unpack8<DT>(ldraw<DT>(x, ((size_t)n * HW + p) * C + chunk * 8), f);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) s[c] += f[c];
-  }
+  const int n = blockIdx.x, tid = threadIdx.x;
   const float inv = 1.f / (float)HW;
+  for (int c0 = 0; c0 < cpr; c0 += 256) {           // groups of 256 chunks (C > 2048: several)
+    const int cw = cpr - c0 < 256 ? cpr - c0 : 256;
+    const int PL = 256 / cw;                        // pixel lanes
+    const int chunk = tid % cw, pl = tid / cw;
+    float s[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) s[c] *= inv;
-  straw<DT>(out, (size_t)n * C + chunk * 8, s);
+    for (int c = 0; c < 8; ++c) s[c] = 0.f;
+    if (pl < PL) {
+      const size_t base = (size_t)n * HW * C + (size_t)(c0 + chunk) * 8;
+      int p = pl;
+      for (; p + 3 * PL < HW; p += 4 * PL) {        // four independent loads in flight
+        Raw8<DT> v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ldraw<DT>(x, base + (size_t)(p + u * PL) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float f[8];
+          unpack8<DT>(v[u], f);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) s[c] += f[c];
+        }
+      }
+      for (; p < HW; p += PL) {
+        float f[8];
+        unpack8<DT>(ldraw<DT>(x, base + (size_t)p * C), f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) s[c] += f[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) red[tid * 8 + c] = s[c];
+    __syncthreads();
+    if (tid < cw) {
+      float t[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) t[c] = 0.f;
+      for (int l = 0; l < PL; ++l) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) t[c] += red[(l * cw + tid) * 8 + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) t[c] *= inv;
+      straw<DT>(out, (size_t)n * C + (size_t)(c0 + tid) * 8, t);
+    }
+    __syncthreads();
+  }
 }
 
 template <int DT>
@@ -169,8 +204,8 @@ void launch_maxpool_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int
 void launch_global_mean_fwd(const void* x, void* out, int N, int HW, int C, int dt,
                             hipStream_t s) {
   if (C % 8) throw std::invalid_argument("global_mean: C %% 8 != 0");
-  DTF_DT_SWITCH(dt, hipLaunchKernelGGL(global_mean_fwd_kernel<DT>, dim3((N * (C / 8) + 255) / 256),
-                                       dim3(256), 0, s, x, out, N, HW, C));
+  DTF_DT_SWITCH(dt, hipLaunchKernelGGL(global_mean_fwd_kernel<DT>, dim3(N), dim3(256), 0, s, x, out,
+                                       N, HW, C));
 }
 
 void launch_global_mean_bwd(const void* dy, void* dx, int N, int HW, int C, int dt,

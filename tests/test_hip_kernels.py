@@ -960,3 +960,18 @@ def test_conv_with_batchnorm_prologue(case, cfg):
     o = out.float().reshape(P, -1)[:, :Cout]
     assert torch.allclose(ostats[:, 0].sum(0), o.sum(0), rtol=1e-2, atol=0.5)
     assert torch.allclose(ostats[:, 1].sum(0), (o * o).sum(0), rtol=1e-2, atol=0.5)
+
+
+@pytest.mark.parametrize("N,HW,C", [(128, 64, 64), (5, 49, 2048), (3, 10, 24), (2, 7, 4096), (4, 1, 8)])
+def test_global_mean_shapes(N, HW, C):
+  """Global average pool (reference `resnet_cifar_model.py:235`, `resnet_model.py:372`): narrow
+  tensors spread their pixels over thread lanes, wide ones their channels; more than 2048
+  channels take several chunk groups."""
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator().manual_seed(N + HW + C)
+  x = _bf(torch.randn(N, HW, C, generator=gen)).to(dev)
+  m = torch.full((N, C), float("nan"), dtype=torch.bfloat16, device=dev)
+  native.run_op("mean_fwd", dict(x=x.data_ptr(), out=m.data_ptr(), N=N, HW=HW, C=C))
+  torch.cuda.synchronize()
+  assert torch.allclose(m.float(), x.float().mean(1), rtol=1e-2, atol=1e-2)
