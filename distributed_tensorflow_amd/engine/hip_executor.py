@@ -847,6 +847,9 @@ class HipExecutor:
     pooled_grad: Dict[str, torch.Tensor] = {}    # fused max-pool name -> gradient of its output
     dual_done: set = set()                       # BatchNorms whose backward ran in a dual launch
     self.bn_ws2 = None
+    bwd_pro: Dict[str, Dict] = {}                # conv output -> BatchNorm backward folded into
+    prologue_limit = int(os.environ.get("DTF_BN_PROLOGUE_BYTES", self.BN_PROLOGUE_BYTES)) \
+        if os.environ.get("DTF_BN_BWD_PROLOGUE", "1") != "0" else 0      # that conv's data gradient
     deferred: Dict[str, List] = {}               # tensor -> strided data gradients waiting for
     defer_ok = os.environ.get("DTF_DEFER_STRIDED_DGRAD", "1") != "0"    # its first writer
     for op in reversed(spec.ops):
@@ -966,6 +969,21 @@ class HipExecutor:
           if dout is None:
             raise RuntimeError("residual BatchNorm %s fed by a deferred gradient" % op.name)
           pending[rname] = (dout, mask_ptr)
+        if self._bwd_prologue_ok(op, producer.get(xname), first_conv, prologue_limit):
+          # small layer: the data gradient of the convolution in front of this BatchNorm applies
+          # the backward formula to dz on its way into LDS and writes dy on the side
+          bwd_pro[xname] = dict(
+              op=op, dz=dz_ptr,
+              fields=dict(bpro_sums=self._bn_pre_stats[op.name], bpro_replicas=self.STATS_REPLICAS,
+                          bpro_y=x.data_ptr(), bpro_mask=mask_ptr, bpro_mean=mean_p,
+                          bpro_invstd=inv_p, bpro_gamma=self._var_ptr(op.name + "/gamma"),
+                          bpro_dgamma=self._var_ptr(op.name + "/gamma", "grad"),
+                          bpro_dbeta=self._var_ptr(op.name + "/beta", "grad"),
+                          bpro_dy=dy.data_ptr(), bpro_P=P))
+          written.add(xname)
+          for t in op.inputs:
+            uses_left[t] = uses_left.get(t, 0) - 1
+          continue
         plan.add("bn_bwd", dict(
             dz=dz_ptr, y=x.data_ptr(), z=None, mask=mask_ptr,
             mean=mean_p, invstd=inv_p,
@@ -978,6 +996,34 @@ class HipExecutor:
             P=P, C=C), op.name + "/bwd")
         written.add(xname)
         done([op.name + "/gamma", op.name + "/beta"])
+      elif op.kind == "conv" and op.output in bwd_pro:
+        # data gradient with the BatchNorm backward of the layer behind it in its operand path;
+        # the weight gradient reads the dy that launch writes, so it is forked behind it
+        g = self.geoms[op.name]
+        bp = bwd_pro.pop(op.output)
+        dx = grad_buf(xname)
+        add, add_mask = None, None
+        if xname in pending and xname not in written:
+          pt, pm = pending.pop(xname)
+          add, add_mask = pt.data_ptr(), pm
+        extra = bwd_stats_for(xname, g.Cin)
+        descs = g.dgrad(bp["dz"], self._wd_ptr(op.name), dx.data_ptr(),
+                        accumulate=xname in written, addend=add, addend_mask=add_mask)
+        assert len(descs) == 1
+        d = descs[0]
+        d.update(extra)
+        d.update(bp["fields"])
+        d["cfg"] = 42 if g.Cin <= 16 else 45        # 64-pixel tiles always hold whole image rows
+        self._add(plan, "conv", d, bp["op"].name + "/bwd+" + op.name + "/dgrad")
+        written.add(xname)
+        for op2, g2, dout2 in deferred.pop(xname, []):
+          for d2 in g2.dgrad(dout2.data_ptr(), self._wd_ptr(op2.name), dx.data_ptr(),
+                             accumulate=True, skip_empty=True):
+            self._add(plan, "conv", d2, op2.name + "/dgrad")
+        self._add_wgrad(plan, g.wgrad(acts[xname].data_ptr(), dout.data_ptr(),
+                                      self._var_ptr(op.name + "/kernel", "grad")),
+                        op.name + "/wgrad")
+        done([bp["op"].name + "/gamma", bp["op"].name + "/beta", op.name + "/kernel"])
       elif op.kind == "conv":
         g = self.geoms[op.name]
         # The weight gradient is forked before the data gradient is enqueued.  Forking it behind
@@ -1020,6 +1066,8 @@ class HipExecutor:
         uses_left[t] = uses_left.get(t, 0) - 1
     if deferred:
       raise RuntimeError("deferred data gradients never issued: %s" % sorted(deferred))
+    if bwd_pro:
+      raise RuntimeError("BatchNorm backward passes never issued: %s" % sorted(bwd_pro))
     self._flush_wgrads(plan)
     if self.overlap_wgrad:
       plan.add("join", {}, "join")               # the step ends with the side lane collected
@@ -1028,6 +1076,27 @@ class HipExecutor:
     left = [i for i, r in remaining.items() if r]
     if left:
       raise RuntimeError("buckets never completed: %s" % left)
+
+  def _bwd_prologue_ok(self, bn: Op, conv: Optional[Op], first_conv: Op, limit: int) -> bool:
+    """True when the backward pass of `bn` can run inside the data gradient of `conv`, the
+    layer that produces its input: the reductions were accumulated by the launch that wrote
+    dz, the convolution is a unit-stride one of a small layer (`conv_halo.hip` serves it with
+    a 64-pixel tile) and has a data gradient at all."""
+    if (limit <= 0 or self.dt not in (0, 1) or bn.name not in self._bn_pre_stats
+        or conv is None or conv.kind != "conv" or conv is first_conv):
+      return False
+    g = self.geoms[conv.name]
+    c = bn.attrs["channels"]
+    pt, _pb, pl, _pr = g.pad
+    k = -(-g.KH * g.KW * g.cout_pad // 32)
+    return (g.mode == "normal" and g.stride == 1 and g.KH % 2 == 1 and g.KW % 2 == 1
+            and pt == g.KH // 2 and pl == g.KW // 2 and g.OH == g.H and g.OW == g.W
+            and g.Cout == c and g.ldc == c and g.Cin % 8 == 0 and g.Cin <= 64
+            and 8 <= c <= 128 and c & (c - 1) == 0
+            and self.acts[bn.inputs[0]].numel() * self.esize <= limit
+            and g.W <= 64 and 64 % g.W == 0 and (g.H * g.W) % 64 == 0
+            and (64 // g.W + g.KH - 1) * (g.W + g.KW - 1) * c * 2 <= 16384
+            and k * min(32, round_up(g.Cin, 16)) * 64 <= 40960)
 
   def _dual_bwd_partner(self, op: Op, dout, mask_ptr, producer, consumers, written,
                         pending) -> Optional[Op]:

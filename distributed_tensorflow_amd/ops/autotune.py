@@ -50,7 +50,7 @@ def signature(kind: str, desc: Dict) -> str:
   """Shape key of a descriptor: every integer field, plus which optional tensors are present."""
   parts = [kind]
   for k in sorted(desc):
-    if k in _IGNORED or (k.startswith("pro_") and k != "pro_relu"):
+    if k in _IGNORED or (k.startswith("pro_") and k != "pro_relu") or k.startswith("bpro_"):
       continue
     parts.append("%s=%s" % (k, desc[k]))
   for k in ("addend", "addend_mask", "bias", "stats", "scale"):
@@ -63,6 +63,8 @@ def signature(kind: str, desc: Dict) -> str:
       parts.append("+" + k)
   if desc.get("pro_sums") is not None:
     parts.append("+pro")           # BatchNorm of the input folded into the launch
+  if desc.get("bpro_sums") is not None:
+    parts.append("+bpro")          # BatchNorm backward of the output's layer folded into a data gradient
   return "|".join(parts)
 
 
@@ -83,7 +85,7 @@ def _fwd_candidates(desc: Dict) -> List[int]:
   # serve falls back to the two-buffer tile of the same footprint, or is refused (ValueError,
   # skipped by the tuner) when it carries a BatchNorm prologue
   halo = [40, 41, 42] if cout <= 16 else [43, 44, 45, 46] if cout <= 32 else [45, 46, 47]
-  if desc.get("pro_sums") is not None:
+  if desc.get("pro_sums") is not None or desc.get("bpro_sums") is not None:
     return halo
   small = desc.get("N", 0) * desc.get("OH", 0) * desc.get("OW", 0) * desc.get("Cpix", 0) <= (8 << 20)
   if not small:

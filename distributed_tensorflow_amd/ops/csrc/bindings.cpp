@@ -82,6 +82,19 @@ ConvParams conv_from_dict(const py::dict& d) {
     p.pro.momentum = get<float>(d, "pro_momentum");
     p.pro.relu = get_or<int>(d, "pro_relu", 0);
   }
+  p.bpro.sums = ptr<const float>(d, "bpro_sums", false);
+  if (p.bpro.sums) {
+    p.bpro.replicas = get<int>(d, "bpro_replicas");
+    p.bpro.y = ptr<const void>(d, "bpro_y");
+    p.bpro.mask = ptr<const uint8_t>(d, "bpro_mask", false);
+    p.bpro.mean = ptr<const float>(d, "bpro_mean");
+    p.bpro.invstd = ptr<const float>(d, "bpro_invstd");
+    p.bpro.gamma = ptr<const float>(d, "bpro_gamma");
+    p.bpro.dgamma = ptr<float>(d, "bpro_dgamma");
+    p.bpro.dbeta = ptr<float>(d, "bpro_dbeta");
+    p.bpro.dy = ptr<void>(d, "bpro_dy");
+    p.bpro.P = get<int>(d, "bpro_P");
+  }
   p.N = get<int>(d, "N"); p.H = get<int>(d, "H"); p.W = get<int>(d, "W");
   p.Cpix = get<int>(d, "Cpix");
   p.OH = get<int>(d, "OH"); p.OW = get<int>(d, "OW");

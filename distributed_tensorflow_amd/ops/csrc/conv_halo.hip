@@ -12,6 +12,10 @@
 // waits once, and runs the K loop out of LDS without a barrier.  A tap is a shifted view of the
 // halo tile, so each pixel is fetched once instead of once per tap.
 //
+// BPRO (BnBackwardPrologue): the mirror image for a data-gradient launch - the BatchNorm backward
+// formula turns dz into dy on the way into the halo tile (constants from the replica sums of the
+// launch that produced dz), dy is written on the side for the weight gradient.
+//
 // PRO (BnPrologue in conv_params.h): the training BatchNorm (+ residual, + ReLU) in front of the
 // layer runs on the pixels' way through registers into the halo tile, x = relu?(y * scale + shift
 // (+ res)); every block derives scale / shift from the sums, block 0 publishes saved and moving
@@ -38,9 +42,11 @@ __device__ __attribute__((aligned(16))) uint32_t g_halo_zero_page[4] = {0u, 0u, 
 
 constexpr int HALO_BYTES = 16384;
 
-template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool PRO>
+// PMODE: 0 plain, 1 BatchNorm prologue (forward), 2 BatchNorm backward prologue (data gradient)
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int PMODE>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2)
 void conv_halo_kernel(const ConvParams p) {
+  constexpr bool PRO = PMODE == 1, BPRO = PMODE == 2;
   typedef typename Elem<DT>::T T;
   static_assert(DT != DT_F32, "16-bit element types");
   constexpr int EPC = 8, BK = 32;
@@ -55,8 +61,13 @@ void conv_halo_kernel(const ConvParams p) {
   static_assert(WM % 16 == 0 && WN % 16 == 0, "tile shape");
 
   __shared__ __attribute__((aligned(16))) uint8_t halo[HALO_BYTES];
-  __shared__ __attribute__((aligned(16))) float pro_sc[PRO ? 128 : 4];
+  __shared__ __attribute__((aligned(16))) float pro_sc[PMODE ? 128 : 4];   // BPRO: gamma * invstd
   __shared__ __attribute__((aligned(16))) float pro_sh[PRO ? 128 : 4];
+  // BPRO: mean, invstd, dbeta / P, dgamma / P per channel
+  __shared__ __attribute__((aligned(16))) float bp_mean[BPRO ? 128 : 4];
+  __shared__ __attribute__((aligned(16))) float bp_inv[BPRO ? 128 : 4];
+  __shared__ __attribute__((aligned(16))) float bp_c1[BPRO ? 128 : 4];
+  __shared__ __attribute__((aligned(16))) float bp_c2[BPRO ? 128 : 4];
   extern __shared__ __attribute__((aligned(16))) uint8_t wres[];     // [KT][BN rows of 64 bytes]
 
   const int tid = threadIdx.x;
@@ -121,8 +132,11 @@ void conv_halo_kernel(const ConvParams p) {
   const int r0 = (m0 - n_img * img) / p.W;
   const int RB = BM / p.W;
   const int total = (RB + p.TI - 1) * HW * cpr;
-  const T* gres = PRO ? reinterpret_cast<const T*>(p.pro.res) : nullptr;
+  // second tensor read alongside the input: PRO the residual (optional), BPRO the BatchNorm input
+  const T* gres = PRO ? reinterpret_cast<const T*>(p.pro.res)
+                      : (BPRO ? reinterpret_cast<const T*>(p.bpro.y) : nullptr);
   u32x4 yv[HCH], rv[HCH];
+  uint32_t mb[HCH];
   size_t hsrc[HCH];
   bool hok[HCH], hown[HCH];
 #pragma unroll
@@ -137,6 +151,10 @@ void conv_halo_kernel(const ConvParams p) {
     yv[u] = hok[u] ? *reinterpret_cast<const u32x4*>(gin + hsrc[u]) : u32x4{0u, 0u, 0u, 0u};
     rv[u] = (hok[u] && gres != nullptr) ? *reinterpret_cast<const u32x4*>(gres + hsrc[u])
                                         : u32x4{0u, 0u, 0u, 0u};
+    mb[u] = 0xffu;
+    if constexpr (BPRO) {
+      if (hok[u] && p.bpro.mask != nullptr) mb[u] = p.bpro.mask[hsrc[u] >> 3];
+    }
   }
 
   // ---- 3. PRO: scale / shift of the input's channels from the producer's sums --------------------
@@ -179,6 +197,37 @@ void conv_halo_kernel(const ConvParams p) {
     __syncthreads();                   // scale / shift visible; `part` has been read
   }
 
+  if constexpr (BPRO) {
+    // the same column sums, of [sum g | sum g*y]; then the constants of the backward formula
+    const int cols = 2 * C;
+    const int RL = NT / cols;
+    const int col = tid % cols, rl = tid / cols;
+    float* part = reinterpret_cast<float*>(halo);
+    if (rl < RL) {
+      float sum = 0.f;
+      for (int g = rl; g < p.bpro.replicas; g += RL) sum += p.bpro.sums[(size_t)g * cols + col];
+      part[rl * cols + col] = sum;
+    }
+    __syncthreads();
+    if (tid < C) {
+      float sg = 0.f, sgy = 0.f;
+      for (int r = 0; r < RL; ++r) { sg += part[r * cols + tid]; sgy += part[r * cols + C + tid]; }
+      const float mean = p.bpro.mean[tid], invstd = p.bpro.invstd[tid];
+      const float dgamma = (sgy - mean * sg) * invstd;
+      const float invP = 1.f / (float)p.bpro.P;
+      pro_sc[tid] = p.bpro.gamma[tid] * invstd;
+      bp_mean[tid] = mean;
+      bp_inv[tid] = invstd;
+      bp_c1[tid] = sg * invP;
+      bp_c2[tid] = dgamma * invP;
+      if (bid == 0) {                  // plain stores into the flat gradient buffer
+        p.bpro.dbeta[tid] = sg;
+        p.bpro.dgamma[tid] = dgamma;
+      }
+    }
+    __syncthreads();
+  }
+
   // ---- 4. halo tile into LDS (normalised on the way with PRO) -------------------------------------
   const bool side = PRO && p.pro.z != nullptr && nt == 0;
 #pragma unroll
@@ -216,6 +265,34 @@ void conv_halo_kernel(const ConvParams p) {
           *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.pro.z) + hsrc[u]) = ov;
           if (p.pro.mask != nullptr) p.pro.mask[hsrc[u] >> 3] = (uint8_t)bits;
         }
+      }
+    }
+    if constexpr (BPRO) {
+      if (hok[u]) {
+        const int c0 = (idx % cpr) * 8;
+        auto ld8 = [&](const float* a, float (&v)[8]) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(a + c0);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(a + c0 + 4);
+          v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+          v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        };
+        float sc[8], mean[8], inv[8], c1[8], c2[8];
+        ld8(pro_sc, sc); ld8(bp_mean, mean); ld8(bp_inv, inv); ld8(bp_c1, c1); ld8(bp_c2, c2);
+        const uint32_t w[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};       // dz
+        const uint32_t yw[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};      // y
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float g0 = (mb[u] >> (2 * j)) & 1u ? lo16<DT>(w[j]) : 0.f;
+          const float g1 = (mb[u] >> (2 * j + 1)) & 1u ? hi16<DT>(w[j]) : 0.f;
+          const float x0 = (lo16<DT>(yw[j]) - mean[2 * j]) * inv[2 * j];
+          const float x1 = (hi16<DT>(yw[j]) - mean[2 * j + 1]) * inv[2 * j + 1];
+          o[j] = pack2<DT>(sc[2 * j] * (g0 - c1[2 * j] - x0 * c2[2 * j]),
+                           sc[2 * j + 1] * (g1 - c1[2 * j + 1] - x1 * c2[2 * j + 1]));
+        }
+        ov = u32x4{o[0], o[1], o[2], o[3]};
+        if (nt == 0 && hown[u])
+          *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.bpro.dy) + hsrc[u]) = ov;
       }
     }
     *reinterpret_cast<u32x4*>(halo + (size_t)idx * 16) = ov;
@@ -283,13 +360,19 @@ void launch_halo_dt(const ConvParams& p, hipStream_t stream) {
   const size_t dyn = (size_t)KT * BN * 64;
   const dim3 block(64 * WAVES_M * WAVES_N);
   if (p.pro.sums)
-    hipLaunchKernelGGL((conv_halo_kernel<DT, BM, BN, WAVES_M, WAVES_N, EPI_PLAIN, true>), dim3(grid),
+    hipLaunchKernelGGL((conv_halo_kernel<DT, BM, BN, WAVES_M, WAVES_N, EPI_PLAIN, 1>), dim3(grid),
+                       block, dyn, stream, p);
+  else if (p.bpro.sums && p.stats_y)
+    hipLaunchKernelGGL((conv_halo_kernel<DT, BM, BN, WAVES_M, WAVES_N, EPI_BSTATS, 2>), dim3(grid),
+                       block, dyn, stream, p);
+  else if (p.bpro.sums)
+    hipLaunchKernelGGL((conv_halo_kernel<DT, BM, BN, WAVES_M, WAVES_N, EPI_PLAIN, 2>), dim3(grid),
                        block, dyn, stream, p);
   else if (p.stats_y)
-    hipLaunchKernelGGL((conv_halo_kernel<DT, BM, BN, WAVES_M, WAVES_N, EPI_BSTATS, false>), dim3(grid),
+    hipLaunchKernelGGL((conv_halo_kernel<DT, BM, BN, WAVES_M, WAVES_N, EPI_BSTATS, 0>), dim3(grid),
                        block, dyn, stream, p);
   else
-    hipLaunchKernelGGL((conv_halo_kernel<DT, BM, BN, WAVES_M, WAVES_N, EPI_PLAIN, false>), dim3(grid),
+    hipLaunchKernelGGL((conv_halo_kernel<DT, BM, BN, WAVES_M, WAVES_N, EPI_PLAIN, 0>), dim3(grid),
                        block, dyn, stream, p);
 }
 

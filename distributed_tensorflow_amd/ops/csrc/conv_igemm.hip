@@ -477,6 +477,16 @@ void validate_conv_params(const ConvParams& p) {
     if (p.dhs != 1 || p.dws != 1 || p.dh0 > 0 || -p.dh0 >= p.TI || p.dw0 > 0 || -p.dw0 >= p.TJ)
       fail("BatchNorm prologue: needs forward taps that cover the output pixel");
   }
+  if (p.bpro.sums) {
+    if (p.pro.sums || p.scale || p.bias) fail("the backward BatchNorm prologue belongs to a training data gradient");
+    if (p.Cpix > 128) fail("backward BatchNorm prologue: at most 128 channels");
+    if (p.bpro.replicas <= 0 || p.bpro.P != p.N * p.H * p.W) fail("backward BatchNorm prologue: bad replica count / sample count");
+    if (!p.bpro.y || !p.bpro.mean || !p.bpro.invstd || !p.bpro.gamma || !p.bpro.dgamma || !p.bpro.dbeta || !p.bpro.dy)
+      fail("backward BatchNorm prologue: missing tensor");
+    // the block's own rows must lie inside its halo tile: the taps cover the output pixel
+    const int oh = p.dhs > 0 ? p.dh0 : p.dh0 - (p.TI - 1), ow = p.dws > 0 ? p.dw0 : p.dw0 - (p.TJ - 1);
+    if (oh > 0 || -oh >= p.TI || ow > 0 || -ow >= p.TJ) fail("backward BatchNorm prologue: the taps must cover the output pixel");
+  }
   if ((p.stats_y || p.stats_mask) && !p.stats) fail("stats_y / stats_mask without a stats buffer");
   if (p.stats_mask && !p.stats_y) fail("stats_mask belongs to the backward statistics (stats_y)");
   if ((p.OH - 1) * p.OSH + p.OOH >= p.OHfull || (p.OW - 1) * p.OSW + p.OOW >= p.OWfull)
@@ -503,10 +513,10 @@ void launch_conv_igemm(const ConvParams& p, int cfg, hipStream_t stream) {
   validate_conv_params(p);
   if (cfg >= 40 && cfg < 48) {
     if (launch_conv_halo(p, cfg, stream)) return;
-    if (p.pro.sums)
+    if (p.pro.sums || p.bpro.sums)
       throw std::invalid_argument("conv: this tile cannot run the layer with a BatchNorm prologue");
     cfg = halo_fallback_cfg(cfg);
-  } else if (p.pro.sums) {
+  } else if (p.pro.sums || p.bpro.sums) {
     throw std::invalid_argument("conv: a BatchNorm prologue needs a tile configuration of conv_halo.hip (40..47)");
   }
   if (cfg >= 16 && cfg < 32) {

@@ -29,6 +29,28 @@ struct BnPrologue {
   int relu = 0;
 };
 
+// The backward counterpart, carried by a data-gradient launch: `in` is dz, the gradient of the
+// *output* of the BatchNorm behind this layer, and the kernel turns it into the gradient of the
+// layer's own output on the way into LDS,
+//   dy = gamma * invstd * (g - dbeta / P - xhat * dgamma / P),   g = dz gated by the ReLU mask,
+// with dbeta = sum g and dgamma = (sum g*y - mean * sum g) * invstd from the replica sums
+// [replicas][2][C] that the launch which produced dz accumulated.  Block 0 stores dgamma / dbeta
+// into the gradient buffer; the blocks of channel tile 0 write dy for their own rows (the operand
+// of this layer's weight gradient).
+struct BnBackwardPrologue {
+  const float* sums = nullptr;     // selects the prologue
+  int replicas = 0;
+  const void* y = nullptr;         // the BatchNorm's input (this layer's output), laid out like `in`
+  const uint8_t* mask = nullptr;   // ReLU bits [pixels][C/8]; null: no ReLU
+  const float* mean = nullptr;
+  const float* invstd = nullptr;
+  const float* gamma = nullptr;
+  float* dgamma = nullptr;
+  float* dbeta = nullptr;
+  void* dy = nullptr;              // side output, laid out like `in`
+  int P = 0;
+};
+
 // Forward / data-gradient gather GEMM; see conv_igemm.hip for the formula.
 struct ConvParams {
   int dt = DT_BF16;                // element type of in / wgt / out / addend (common.h)
@@ -57,6 +79,7 @@ struct ConvParams {
   const bf16_t* stats_y = nullptr;
   const uint8_t* stats_mask = nullptr;
   BnPrologue pro;
+  BnBackwardPrologue bpro;
   int N = 0, H = 0, W = 0, Cpix = 0;
   int OH = 0, OW = 0, M = 0;       // logical output grid; M = N*OH*OW
   int OHfull = 0, OWfull = 0, ldc = 0;

@@ -500,12 +500,13 @@ def test_deterministic_mode_is_bitwise_reproducible():
 
 def test_batchnorm_prologue_plan_matches_separate_sweeps(monkeypatch):
   """ResNet-20 (reference `resnet_cifar_model.py:221-241`): BatchNorm layers whose first consumer is
-  a unit-stride convolution run inside that convolution (plain and residual form).  The plan is
-  one launch shorter per such layer and gives the same loss, activations, moving statistics and
-  gradients as separate sweeps.  Both normalise in fp32 and round once, and both accumulate the
-  statistics with float atomics, so two runs of the *same* plan already differ in the last
-  bf16 bit of some activations; the gradient comparison is therefore made against that
-  run-to-run agreement."""
+  a unit-stride convolution run inside that convolution (plain and residual form), and the
+  backward pass of a BatchNorm behind a unit-stride convolution runs inside that convolution's
+  data gradient.  Either plan is one launch shorter per such layer and gives the same loss,
+  activations, moving statistics and gradients as separate sweeps.  All plans normalise in fp32
+  and round once, and all accumulate the statistics with float atomics, so two runs of the *same*
+  plan already differ in the last bf16 bit of some activations; the gradient comparison is
+  therefore made against that run-to-run agreement."""
   from distributed_tensorflow_amd.engine.hip_executor import HipExecutor
   dev = torch.device("cuda")
   spec = models.resnet20()
@@ -514,21 +515,26 @@ def test_batchnorm_prologue_plan_matches_separate_sweeps(monkeypatch):
   x = torch.randn(N, 32, 32, 3, generator=g).to(dev)
   y = torch.randint(0, 10, (N,), generator=g).to(dev)
   runs = []
-  for limit in ("0", "0", None):
-    if limit is None:
-      monkeypatch.delenv("DTF_BN_PROLOGUE_BYTES", raising=False)
-    else:
-      monkeypatch.setenv("DTF_BN_PROLOGUE_BYTES", limit)
+  for fwd, bwd in (("0", "0"), ("0", "0"), (None, "0"), (None, None)):
+    for key, val in (("DTF_BN_PROLOGUE_BYTES", fwd), ("DTF_BN_BWD_PROLOGUE", bwd)):
+      if val is None:
+        monkeypatch.delenv(key, raising=False)
+      else:
+        monkeypatch.setenv(key, val)
     st = ParamStore(spec, dev, 3)
     ex = HipExecutor(spec, st, N, "bf16", st.make_buckets(1), use_graph=False)
     loss, _ = ex.train_step(x, y)
     torch.cuda.synchronize()
     runs.append((ex, st, loss.item()))
-  (ea, sa, la), (_e2, s2, _l2), (eb, sb, lb) = runs
+  (ea, sa, la), (_e2, s2, _l2), (eb, sb, lb), (ec, sc, lc) = runs
   assert not ea._bn_prologue and len(eb._bn_prologue) >= 12
   assert ea.fwd_plan.size() - eb.fwd_plan.size() == len(eb._bn_prologue)
   assert any(len(o.inputs) > 1 for o in spec.ops if o.name in eb._bn_prologue)   # residual form too
-  assert abs(la - lb) <= 2e-2 * abs(la)
+  assert ea.bwd_plan.size() == eb.bwd_plan.size()
+  assert eb.bwd_plan.size() - ec.bwd_plan.size() >= 12        # backward passes folded into data gradients
+  names = [ec.bwd_plan.name(i) for i in range(ec.bwd_plan.size())]
+  assert sum("/bwd+" in n for n in names) == eb.bwd_plan.size() - ec.bwd_plan.size()
+  assert abs(la - lb) <= 2e-2 * abs(la) and abs(la - lc) <= 2e-2 * abs(la)
   # a fused layer's normalised tensor is the one the sweep writes
   for name in list(eb._bn_prologue)[:3]:
     b = next(o for o in spec.ops if o.name == name)
@@ -540,5 +546,13 @@ def test_batchnorm_prologue_plan_matches_separate_sweeps(monkeypatch):
 
   floor = cosine(sa, s2)
   assert cosine(sa, sb) > min(0.99, floor - 0.03), (cosine(sa, sb), floor)
+  assert cosine(sa, sc) > min(0.99, floor - 0.03), (cosine(sa, sc), floor)
+  # BatchNorm parameter gradients come out of the fused data gradients
+  ent = sa.entries
+  some = next(n for n in names if "/bwd+" in n).split("/bwd+")[0]
+  e = ent[some + "/gamma"]
+  ga, gc = sa.grads[e.offset:e.offset + e.size], sc.grads[e.offset:e.offset + e.size]
+  assert torch.allclose(ga, gc, rtol=0.1, atol=0.05 * ga.abs().max().item() + 1e-3)
   # moving statistics were updated by the fused launches as well
   assert torch.allclose(sa.state, sb.state, rtol=1e-2, atol=1e-3)
+  assert torch.allclose(sa.state, sc.state, rtol=1e-2, atol=1e-3)

@@ -975,3 +975,79 @@ def test_global_mean_shapes(N, HW, C):
   native.run_op("mean_fwd", dict(x=x.data_ptr(), out=m.data_ptr(), N=N, HW=HW, C=C))
   torch.cuda.synchronize()
   assert torch.allclose(m.float(), x.float().mean(1), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("cfg", list(range(40, 48)))
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, K, Cout, relu
+    (3, 32, 32, 16, 3, 16, 1), (5, 16, 16, 32, 3, 32, 1), (3, 8, 8, 64, 3, 64, 0),
+    (2, 16, 8, 24, 3, 16, 1), (2, 8, 16, 40, 1, 32, 1),
+])
+def test_dgrad_with_batchnorm_backward_prologue(case, cfg):
+  """BatchNorm backward folded into the data gradient of the layer in front of it (reference
+  layer pairs `resnet_cifar_model.py:75-92`): the launch takes dz (gradient of the BatchNorm
+  output), the layer's output y, the ReLU mask and the replica sums (sum g, sum g*y), and must
+  produce what the separate sweep + data gradient produce: dgamma, dbeta, dy (written on the side)
+  and dX = conv^T(dy)."""
+  from distributed_tensorflow_amd.ops.conv_plan import FWD_CFGS
+  native = _native()
+  N, H, W, Cin, K, Cout, relu = case
+  dev = torch.device("cuda")
+  gen = torch.Generator(device="cpu").manual_seed(hash(case) & 0xffff)
+  pad = same_padding(H, K, 1) + same_padding(W, K, 1)
+  g = ConvGeom(N, H, W, Cin, K, K, Cout, 1, pad)
+  P = N * H * W
+  y = _bf(torch.randn(N, H, W, Cout, generator=gen) * 1.3 + 0.2).to(dev)      # the layer's output
+  dz = _bf(torch.randn(N, H, W, Cout, generator=gen)).to(dev)
+  bits = (torch.rand(N, H, W, Cout, generator=gen) > 0.4).to(dev) if relu else None
+  gamma = (torch.rand(Cout, generator=gen) + 0.5).to(dev)
+  w = (torch.randn(K, K, Cin, Cout, generator=gen) * (1.0 / math.sqrt(K * K * Cin))).to(dev)
+  flat = y.float().reshape(P, Cout)
+  mean, var = flat.mean(0), flat.var(0, unbiased=False)
+  invstd = torch.rsqrt(var + 1e-5)
+  gm = dz.float() * bits if relu else dz.float()
+  gf = gm.reshape(P, Cout)
+  R = 32
+  rows = torch.arange(P, device=dev) % R
+  sums = torch.zeros(R, 2, Cout, device=dev)
+  sums[:, 0].index_add_(0, rows, gf)
+  sums[:, 1].index_add_(0, rows, gf * flat)
+  mask = None
+  if relu:
+    mask = (bits.view(P, Cout // 8, 8).to(torch.int32) << torch.arange(8, device=dev)).sum(-1).to(torch.uint8)
+    mask = mask.flatten().contiguous()
+  saved = torch.cat([mean, invstd]).contiguous()
+  dgamma = torch.zeros(Cout, device=dev)
+  dbeta = torch.zeros(Cout, device=dev)
+  dy = torch.full((N, H, W, Cout), float("nan"), dtype=torch.bfloat16, device=dev)
+  dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=dev)
+  wd = _pack(native, g, w, "dgrad")
+  descs = g.dgrad(dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), cfg=cfg)
+  assert len(descs) == 1
+  d = descs[0]
+  d.update(bpro_sums=sums.data_ptr(), bpro_replicas=R, bpro_y=y.data_ptr(),
+           bpro_mask=mask.data_ptr() if relu else None, bpro_mean=saved.data_ptr(),
+           bpro_invstd=saved.data_ptr() + 4 * Cout, bpro_gamma=gamma.data_ptr(),
+           bpro_dgamma=dgamma.data_ptr(), bpro_dbeta=dbeta.data_ptr(), bpro_dy=dy.data_ptr(), bpro_P=P)
+  BM, BN = FWD_CFGS[cfg]
+  fits = BM % W == 0 and (H * W) % BM == 0 and (BM // W + K - 1) * (W + K - 1) * Cout * 2 <= 16384 \
+      and -(-K * K * Cout // 32) * BN * 64 <= 40960
+  if not fits:
+    with pytest.raises(ValueError):
+      native.run_op("conv", d)
+    return
+  native.run_op("conv", d)
+  torch.cuda.synchronize()
+  xhat = (flat - mean) * invstd
+  dbeta_ref = gf.sum(0)
+  dgamma_ref = (gf * xhat).sum(0)
+  dy_ref = (gamma * invstd * (gf - dbeta_ref / P - xhat * dgamma_ref / P)).view(N, H, W, Cout)
+  assert torch.allclose(dbeta, dbeta_ref, rtol=1e-2, atol=5e-2)
+  assert torch.allclose(dgamma, dgamma_ref, rtol=1e-2, atol=5e-2)
+  assert torch.isfinite(dy.float()).all()
+  assert torch.allclose(dy.float(), dy_ref, rtol=3e-2, atol=3e-2)
+  # the data gradient consumes exactly the dy it wrote
+  xr = torch.zeros(N, H, W, Cin, device=dev, requires_grad=True)
+  _ref_conv(xr, _bf(w).float(), 1, pad).backward(dy.float())
+  err = (dx.float() - xr.grad).abs().max().item()
+  assert err <= 0.02 * xr.grad.abs().max().item() + 1e-2, err
