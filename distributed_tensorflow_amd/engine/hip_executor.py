@@ -380,7 +380,11 @@ class HipExecutor:
     self.eval_plan = _TypedPlan(ext.Plan(), self.dt)
     self.bwd_plan = _TypedPlan(ext.Plan(), self.dt)
     self._build_forward(self.fwd_plan, training=True)
+    hot_after_forward = (dict(self._sweep_hot), self._sweep_clock)
     self._build_forward(self.eval_plan, training=False)
+    # the backward plan runs behind the training forward plan: it continues that plan's record
+    # of which end of each tensor is still cached
+    self._sweep_hot, self._sweep_clock = hot_after_forward
     self._build_backward(consumers)
     autotune.save()
     self.probs = None
@@ -515,12 +519,66 @@ class HipExecutor:
                            descs=self.pack_descs.data_ptr(), ndesc=len(descs), nblocks=blk,
                            dt=self.dt)
 
+  # ---- sweep directions --------------------------------------------------------------------
+  # The GPU's 256 MB memory-side cache keeps what the last launches touched.  A launch that walks
+  # a large tensor front to back leaves the tensor's *tail* there; the next launch over that
+  # tensor finds it only if it starts at the tail.  Every planned launch therefore picks its
+  # direction from where the tensors it touches were left hot, and leaves its own mark.
+  SWEEP_CACHE_BYTES = 256 << 20
+  SWEEP_MIN_BYTES = 24 << 20          # smaller tensors stay cached whole: direction irrelevant
+
+  def _sweep_dir(self, tensors: List[Tuple[Optional[int], int]], mark: bool = True) -> int:
+    """1 when the launch touching `tensors` ((address, bytes) pairs) should run back to front.
+
+    Votes by bytes: a tensor whose hot end is its tail (last walked front to back, less than a
+    cache's worth of traffic ago) votes for a reversed walk, one left hot at the head for a
+    forward walk.  With `mark` the launch's own walk is recorded on every tensor it touches
+    (side-lane launches only vote: they run next to the main lane's launches, not before them)."""
+    mode = os.environ.get("DTF_SWEEP_ORDER", "auto")
+    if mode == "0":
+      return 0
+    hot = self.__dict__.setdefault("_sweep_hot", {})
+    clock = self.__dict__.get("_sweep_clock", 0)
+    vote = 0
+    for ptr, nbytes in tensors:
+      if ptr is None or nbytes < self.SWEEP_MIN_BYTES:
+        continue
+      h = hot.get(ptr)
+      if h is not None and clock - h[1] < self.SWEEP_CACHE_BYTES:
+        vote += nbytes if h[0] else -nbytes       # h[0]: 1 = tail is hot
+    rev = 1 if vote > 0 else 0
+    if not mark:
+      return rev
+    total = sum(n for p, n in tensors if p is not None)
+    clock += total
+    self._sweep_clock = clock
+    for ptr, nbytes in tensors:
+      if ptr is not None:
+        hot[ptr] = (0 if rev else 1, clock)
+    return rev
+
+  def _conv_tensors(self, desc: Dict) -> List[Tuple[Optional[int], int]]:
+    e = self.esize
+    nin = desc["N"] * desc["H"] * desc["W"] * desc["Cpix"] * e
+    nout = desc["N"] * desc.get("OHfull", desc["OH"]) * desc.get("OWfull", desc["OW"]) \
+        * desc.get("ldc", desc["Cout"]) * e
+    return [(desc.get("in"), nin), (desc.get("out"), nout), (desc.get("addend"), nout),
+            (desc.get("stats_y"), nout)]
+
   def _add(self, plan, kind: str, desc: Dict, name: str, lane: int = 0):
     """plan.add with the measured tile configuration of this shape, when one is known."""
     if kind in ("conv", "wgrad"):
       desc = autotune.apply(kind, desc)
     if kind == "wgrad" and self.deterministic:
       desc = dict(desc, splits=1)
+    if kind == "conv" and "rev" not in desc and desc.get("pro_sums") is None \
+        and desc.get("bpro_sums") is None:
+      desc = dict(desc, rev=self._sweep_dir(self._conv_tensors(desc)))
+    elif kind == "wgrad" and "rev" not in desc and desc.get("batch") is None:
+      e = self.esize
+      tensors = [(desc.get("x"), desc["N"] * desc["H"] * desc["W"] * desc["Cpix"] * e),
+                 (desc.get("dy"), desc["N"] * desc["OH"] * desc["OW"] * desc.get("ldy", desc["Cout"]) * e)]
+      desc = dict(desc, rev=self._sweep_dir(tensors, mark=lane == 0))
     plan.add(kind, desc, name, lane)
 
   def _add_wgrad(self, plan, desc: Dict, name: str):
@@ -577,6 +635,7 @@ class HipExecutor:
   def _build_forward(self, plan, training: bool):
     spec, N = self.spec, self.N
     acts = self.acts
+    self._sweep_hot, self._sweep_clock = {}, 0
     plan.add("memset", dict(ptr=self.accum.data_ptr(), nbytes=8), "zero_loss")
     plan.add("preprocess_pad", self._pre, "preprocess")
     if training and (self._bn_stats_off or self._bn_bwd_stats_off):
@@ -677,6 +736,10 @@ class HipExecutor:
             cs = src.attrs["channels"]
             common["res"] = acts[src.inputs[0]].data_ptr()
             extra.update(rscale=sp + 8 * cs, rshift=sp + 12 * cs)
+          if extra.get("apply", 1):
+            nb = x.numel() * self.esize
+            extra["rev"] = self._sweep_dir([(common["y"], nb), (common["res"], nb),
+                                            (common["z"], nb)])
           plan.add("bn_fwd_train", dict(
               save_mean=mean_p, save_invstd=mean_p + 4 * C, scale=mean_p + 8 * C,
               shift=mean_p + 12 * C, ws=ws, fused_replicas=self.STATS_REPLICAS if fused else 0,
@@ -938,7 +1001,12 @@ class HipExecutor:
           m2 = self.bn_saved.data_ptr() + 4 * self._bn_off[partner.name]
           if self.bn_ws2 is None:
             self.bn_ws2 = self._alloc((native.ext().bn_workspace_floats(),), torch.float32)
+          nb = x.numel() * self.esize
+          rr = self._sweep_dir([(dz_ptr, nb), (x.data_ptr(), nb), (acts[x2].data_ptr(), nb)])
+          ra = self._sweep_dir([(dz_ptr, nb), (x.data_ptr(), nb), (acts[x2].data_ptr(), nb),
+                                (dy.data_ptr(), nb), (grad_buf(x2).data_ptr(), nb)])
           plan.add("bn_bwd_dual", dict(
+              rev_reduce=rr, rev_apply=ra,
               dz=dz_ptr, mask=mask_ptr, P=P, C=C, ws=self.bn_ws.data_ptr(),
               ws2=self.bn_ws2.data_ptr(),
               y=x.data_ptr(), mean=mean_p, invstd=inv_p, gamma=self._var_ptr(op.name + "/gamma"),
@@ -984,7 +1052,13 @@ class HipExecutor:
           for t in op.inputs:
             uses_left[t] = uses_left.get(t, 0) - 1
           continue
+        nb = x.numel() * self.esize
+        rr = 0
+        if op.name not in self._bn_pre_stats:
+          rr = self._sweep_dir([(dz_ptr, nb), (x.data_ptr(), nb)])
+        ra = self._sweep_dir([(dz_ptr, nb), (x.data_ptr(), nb), (dy.data_ptr(), nb)])
         plan.add("bn_bwd", dict(
+            rev_reduce=rr, rev_apply=ra,
             dz=dz_ptr, y=x.data_ptr(), z=None, mask=mask_ptr,
             mean=mean_p, invstd=inv_p,
             gamma=self._var_ptr(op.name + "/gamma"),

@@ -26,7 +26,7 @@ __all__ = ["signature", "lookup", "apply", "tune", "save", "enabled", "CACHE_PAT
 CACHE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
 _POINTERS = ("in", "wgt", "out", "addend", "addend_mask", "bias", "stats", "stats_y",
              "stats_mask", "x", "dy", "dw", "scale", "batch")
-_IGNORED = _POINTERS + ("cfg", "splits", "stats_replicas")
+_IGNORED = _POINTERS + ("cfg", "splits", "stats_replicas", "rev")
 _cache: Optional[Dict[str, Dict[str, int]]] = None
 _dirty = False
 

@@ -114,6 +114,7 @@ ConvParams conv_from_dict(const py::dict& d) {
   p.wk0 = get_or<int>(d, "wk0", 0);
   p.wsi = get_or<int>(d, "wsi", p.TJ * p.Ctap);
   p.wsj = get_or<int>(d, "wsj", p.Ctap);
+  p.rev = get_or<int>(d, "rev", 0);
   p.divOW = make_fastdiv((uint32_t)p.OW);
   p.divOH = make_fastdiv((uint32_t)p.OH);
   return p;
@@ -146,6 +147,7 @@ WgradParams wgrad_from_dict(const py::dict& d) {
   p.TJreal = get_or<int>(d, "TJreal", p.TJpad);
   p.splits = get_or<int>(d, "splits", 1);
   p.debug_plain_store = get_or<int>(d, "debug_plain_store", 0);
+  p.rev = get_or<int>(d, "rev", 0);
   int pps = (p.P + p.splits - 1) / p.splits;
   pps = ((pps + 31) / 32) * 32;
   p.pix_per_split = pps;
@@ -186,9 +188,10 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     // residual = input of another BatchNorm, normalised on the fly with that layer's constants
     auto rscale = ptr<const float>(d, "rscale", false); auto rshift = ptr<const float>(d, "rshift", false);
     const int apply = get_or<int>(d, "apply", 1);      // 0: statistics + finalize only
+    const int rev = get_or<int>(d, "rev", 0);          // the apply sweep runs back to front
     return [=](hipStream_t s) {
       launch_bn_fwd_train(y, res, z, mask, gamma, beta, mm, mv, smean, sinv, scale, shift, ws,
-                          fused, P, C, eps, mom, relu, rscale, rshift, apply, dt, s);
+                          fused, P, C, eps, mom, relu, rscale, rshift, apply, rev, dt, s);
     };
   }
   if (kind == "bn_pool_fwd_train" || kind == "bn_pool_bwd") {
@@ -246,8 +249,10 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     // gradient launches that produced dz; the reduction sweep is skipped
     const int pre = get_or<int>(d, "pre_replicas", 0);
     auto tail = ptr<float>(d, "tail", false);
+    // direction of the two sweeps: bit 0 reduction, bit 1 apply run back to front
+    const int rev = get_or<int>(d, "rev_reduce", 0) | (get_or<int>(d, "rev_apply", 0) << 1);
     return [=](hipStream_t s) {
-      launch_bn_bwd(dz, y, z, mask, mean, inv, gamma, dgamma, dbeta, dy, dres, ws, P, C, pre, tail, dt, s);
+      launch_bn_bwd(dz, y, z, mask, mean, inv, gamma, dgamma, dbeta, dy, dres, ws, P, C, pre, tail, rev, dt, s);
     };
   }
   if (kind == "bn_bwd_dual") {
@@ -262,9 +267,10 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     auto db1 = ptr<float>(d, "dbeta"); auto db2 = ptr<float>(d, "dbeta2");
     auto dy1 = ptr<void>(d, "dy"); auto dy2 = ptr<void>(d, "dy2");
     auto tail = ptr<float>(d, "tail", false);
+    const int rev = get_or<int>(d, "rev_reduce", 0) | (get_or<int>(d, "rev_apply", 0) << 1);
     return [=](hipStream_t s) {
       launch_bn_bwd_dual(dz, mask, P, C, ws, ws2, y1, m1, i1, g1, dg1, db1, dy1, y2, m2, i2, g2, dg2,
-                         db2, dy2, tail, dt, s);
+                         db2, dy2, tail, rev, dt, s);
     };
   }
   if (kind == "mask_apply") {

@@ -218,6 +218,7 @@ struct BnApplyArgs {
   // no ReLU) plus that layer's scale / shift: res := res * rscale + rshift on the fly, so the
   // shortcut's normalised tensor is never written or read back.
   const float* rscale; const float* rshift;
+  int rev;                  // 1: passes over the rows run back to front (set by the launch plan)
 };
 
 // Column sums of G rows of `cols` floats (cols = 2 * C <= 512, a power of two >= 16) by one
@@ -305,20 +306,24 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
   }
   constexpr int U = 4;
   const int stride = gridDim.x * rpb;
-  for (int row0 = blockIdx.x * rpb; row0 < a.P; row0 += U * stride) {
+  const int npass = (a.P + stride - 1) / stride;
+  for (int p0 = 0; p0 < npass; p0 += U) {
     Raw8<DT> yq[U], rq[U];
     bool valid[U];
+    int prow[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int row = row0 + u * stride + rowid;
-      valid[u] = row < a.P;
+      const int p = p0 + u;
+      prow[u] = blockIdx.x * rpb + (a.rev ? npass - 1 - p : p) * stride;
+      const int row = prow[u] + rowid;
+      valid[u] = p < npass && row < a.P;
       const size_t off = (size_t)row * C + chunk * 8;
       yq[u] = valid[u] ? ldraw<DT>(a.y, off) : zero_raw<DT>();
       rq[u] = (valid[u] && a.res) ? ldraw<DT>(a.res, off) : zero_raw<DT>();
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int prow0 = row0 + u * stride;
+      const int prow0 = prow[u];
       const size_t off = (size_t)(prow0 + rowid) * C + chunk * 8;
       float f[8];
       uint32_t bits = 0;
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
         }
         straw<DT>(a.z, off, f);
       }
-      if (a.relu && a.mask && prow0 < a.P) {         // block-uniform condition
+      if (a.relu && a.mask && p0 + u < npass && prow0 < a.P) {   // block-uniform condition
         uint32_t w = bits << (8 * (threadIdx.x & 3));
         w |= __shfl_xor(w, 1);
         w |= __shfl_xor(w, 2);
@@ -376,6 +381,7 @@ struct BnBwdArgs {
   // [dgamma | dbeta] that the blocks add to, `ticket` counts finished blocks; the last one sums
   // the rows, stores dgamma / dbeta and leaves rows and ticket zeroed for the next launch.
   unsigned int* ticket;
+  int rev_reduce, rev_apply;   // passes of the reduction / apply sweep run back to front
 };
 
 constexpr int TAIL_REPLICAS = 8;
@@ -423,24 +429,30 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
       for (int c = 0; c < 8; ++c) part2[c] += g[c] * ((y2v[c] - mean2[c]) * invstd2[c]);
     }
   };
+  // Passes (one row per thread, `stride` rows per pass) in ascending or descending order: the
+  // thread's rows are  r0 + p * stride  for p in [0, np).
   const int stride = gridDim.x * rpb;
-  int row = blockIdx.x * rpb + rowid;
-  for (; row + 3 * stride < a.P; row += 4 * stride) {      // four rows of loads in flight
+  const int r0 = blockIdx.x * rpb + rowid;
+  const int np = r0 < a.P ? (a.P - r0 + stride - 1) / stride : 0;
+  const int first = a.rev_reduce ? r0 + (np - 1) * stride : r0;
+  const int step = a.rev_reduce ? -stride : stride;
+  int row = first, p = 0;
+  for (; p + 3 < np; p += 4, row += 4 * step) {      // four rows of loads in flight
     Raw8<DT> gv[4], yq[4], zq[4], y2q[4];
     uint32_t bits[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const size_t off = (size_t)(row + u * stride) * C + chunk * 8;
+      const size_t off = (size_t)(row + u * step) * C + chunk * 8;
       gv[u] = ldraw<DT>(a.dz, off);
       yq[u] = ldraw<DT>(a.y, off);
       zq[u] = mode == 1 ? ldraw<DT>(a.z, off) : zero_raw<DT>();
-      bits[u] = mode == 2 ? a.mask[(size_t)(row + u * stride) * tpr + chunk] : 0u;
+      bits[u] = mode == 2 ? a.mask[(size_t)(row + u * step) * tpr + chunk] : 0u;
       y2q[u] = NB == 2 ? ldraw<DT>(a.y2, off) : zero_raw<DT>();
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) accumulate(gv[u], yq[u], zq[u], bits[u], y2q[u]);
   }
-  for (; row < a.P; row += stride) {
+  for (; p < np; ++p, row += step) {
     const size_t off = (size_t)row * C + chunk * 8;
     const Raw8<DT> gv = ldraw<DT>(a.dz, off);
     const Raw8<DT> yq = ldraw<DT>(a.y, off);
@@ -603,24 +615,28 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
     }
   };
   const int stride = gridDim.x * rpb;
-  int row = blockIdx.x * rpb + rowid;
-  for (; row + 3 * stride < a.P; row += 4 * stride) {      // four rows of loads in flight
+  const int r0 = blockIdx.x * rpb + rowid;
+  const int np = r0 < a.P ? (a.P - r0 + stride - 1) / stride : 0;
+  const int first = a.rev_apply ? r0 + (np - 1) * stride : r0;
+  const int step = a.rev_apply ? -stride : stride;
+  int row = first, p = 0;
+  for (; p + 3 < np; p += 4, row += 4 * step) {      // four rows of loads in flight
     Raw8<DT> gv[4], yq[4], zq[4], y2q[4];
     uint32_t bits[4];
     size_t off[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      off[u] = (size_t)(row + u * stride) * C + chunk * 8;
+      off[u] = (size_t)(row + u * step) * C + chunk * 8;
       gv[u] = ldraw<DT>(a.dz, off[u]);
       yq[u] = ldraw<DT>(a.y, off[u]);
       zq[u] = mode == 1 ? ldraw<DT>(a.z, off[u]) : zero_raw<DT>();
-      bits[u] = mode == 2 ? a.mask[(size_t)(row + u * stride) * tpr + chunk] : 0u;
+      bits[u] = mode == 2 ? a.mask[(size_t)(row + u * step) * tpr + chunk] : 0u;
       y2q[u] = NB == 2 ? ldraw<DT>(a.y2, off[u]) : zero_raw<DT>();
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) finish(gv[u], yq[u], zq[u], bits[u], off[u], y2q[u]);
   }
-  for (; row < a.P; row += stride) {
+  for (; p < np; ++p, row += step) {
     const size_t off = (size_t)row * C + chunk * 8;
     const Raw8<DT> gv = ldraw<DT>(a.dz, off);
     const Raw8<DT> yq = ldraw<DT>(a.y, off);
@@ -978,8 +994,8 @@ void launch_bn_fwd_train(const void* y, const void* res, void* z, uint8_t* mask,
                          const float* gamma, const float* beta, float* mm, float* mv,
                          float* save_mean, float* save_invstd, float* scale, float* shift,
                          float* ws, int fused_replicas, int P, int C, float eps, float momentum,
-                         int relu, const float* rscale, const float* rshift, int apply, int dt,
-                         hipStream_t s) {
+                         int relu, const float* rscale, const float* rshift, int apply, int rev,
+                         int dt, hipStream_t s) {
   check_channels(C, P);
   if ((rscale == nullptr) != (rshift == nullptr) || (rscale && !res))
     throw std::invalid_argument("bn_fwd_train: rscale / rshift come together, with res");
@@ -993,7 +1009,8 @@ void launch_bn_fwd_train(const void* y, const void* res, void* z, uint8_t* mask,
     return !(e && e[0] == '0');
   }();
   BnApplyArgs a{y, res, z, mask, scale, shift, gamma, beta, mm, mv, P, C, eps, relu,
-                ws, G, momentum, mm, mv, save_mean, save_invstd, scale, shift, rscale, rshift};
+                ws, G, momentum, mm, mv, save_mean, save_invstd, scale, shift, rscale, rshift,
+                rev};
   if (apply && fold_ok && fused_replicas > 0 && fused_replicas * 2 * C <= 16384 &&
       C <= FOLD_MAX_C) {
     DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_apply_kernel<DT, true>), dim3(rows_grid(P, C)),
@@ -1076,7 +1093,7 @@ void launch_bn_pool_bwd(const void* dzp, const uint8_t* idx, const void* y, cons
   }
   BnBwdArgs b{nullptr, y, nullptr, nullptr, mean, invstd, gamma, dgamma, dbeta, dy, nullptr, ws, G,
               N * H * W, C, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-              nullptr};
+              nullptr, 0, 0};
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, b);
   const int ga = rows < 8192 ? rows : 8192;
   if (quad) {
@@ -1105,7 +1122,7 @@ void launch_bn_infer(const void* y, const void* res, void* z, const float* gamma
   check_channels(C, P);
   BnApplyArgs a{y, res, z, nullptr, nullptr, nullptr, gamma, beta, mm, mv, P, C, eps, relu,
                 nullptr, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                nullptr, nullptr};
+                nullptr, nullptr, 0};
   DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_apply_kernel<DT, false>), dim3(rows_grid(P, C)),
                                        dim3(TPB), 0, s, a));
 }
@@ -1115,13 +1132,14 @@ size_t bn_tail_floats() { return 16 + 2 * (size_t)TAIL_REPLICAS * 2 * 2048; }
 void launch_bn_bwd(const void* dz, const void* y, const void* z, const uint8_t* mask,
                    const float* mean, const float* invstd, const float* gamma, float* dgamma,
                    float* dbeta, void* dy, void* dres, float* ws, int P, int C,
-                   int pre_replicas, float* tail, int dt, hipStream_t s) {
+                   int pre_replicas, float* tail, int rev, int dt, hipStream_t s) {
   check_channels(C, P);
   if (pre_replicas < 0) throw std::invalid_argument("bn_bwd: negative replica count");
   const int G = pre_replicas > 0 ? pre_replicas : reduce_grid(P, C);
   BnBwdArgs a{dz, y, z, mask, mean, invstd, gamma, dgamma, dbeta, dy, dres, ws, G, P, C,
               pre_replicas > 0 ? 1 : 0,
-              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+              rev & 1, (rev >> 1) & 1};
   static const bool fold_ok = [] {
     const char* e = std::getenv("DTF_BN_FOLD_FINALIZE");
     return !(e && e[0] == '0');
@@ -1158,12 +1176,13 @@ void launch_bn_bwd_dual(const void* dz, const uint8_t* mask, int P, int C, float
                         const float* gamma1, float* dgamma1, float* dbeta1, void* dy1,
                         const void* y2, const float* mean2, const float* invstd2,
                         const float* gamma2, float* dgamma2, float* dbeta2, void* dy2,
-                        float* tail, int dt, hipStream_t s) {
+                        float* tail, int rev, int dt, hipStream_t s) {
   check_channels(C, P);
   if (ws == ws2) throw std::invalid_argument("bn_bwd_dual: the two layers need separate workspaces");
   const int G = reduce_grid(P, C);
   BnBwdArgs a{dz, y1, nullptr, mask, mean1, invstd1, gamma1, dgamma1, dbeta1, dy1, nullptr, ws, G,
-              P, C, 0, y2, mean2, invstd2, gamma2, dgamma2, dbeta2, dy2, ws2, nullptr};
+              P, C, 0, y2, mean2, invstd2, gamma2, dgamma2, dbeta2, dy2, ws2, nullptr,
+              rev & 1, (rev >> 1) & 1};
   if (tail != nullptr) {
     BnBwdArgs t = a;
     t.ticket = reinterpret_cast<unsigned int*>(tail);

@@ -115,9 +115,10 @@ void conv_igemm_kernel(const ConvParams p) {
   const int tilesM = (p.M + BM - 1) / BM;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
-  const int mt = (slot / tilesN) * 8 + xcd;
+  int mt = (slot / tilesN) * 8 + xcd;
   const int nt = slot % tilesN;
   if (mt >= tilesM) return;
+  if (p.rev) mt = tilesM - 1 - mt;
   const int m0 = mt * BM, n0 = nt * BN;
 
   // ---- per-thread load geometry ----------------------------------------------------

@@ -89,6 +89,10 @@ struct ConvParams {
   int ISH = 1, ISW = 1;
   int dh0 = 0, dhs = 0, dw0 = 0, dws = 0;
   int ldw = 0, wk0 = 0, wsi = 0, wsj = 0;
+  // 1: pixel tiles are handed out back to front.  The launch plan alternates the direction of
+  // consecutive launches over one tensor, so that each starts on the rows the one before it
+  // touched last (still held by the 256 MB memory-side cache).
+  int rev = 0;
   FastDiv divOW, divOH;
 };
 
@@ -117,6 +121,7 @@ struct WgradParams {
   int Cpad = 0, Creal = 0, TJpad = 1, TJreal = 1;
   int splits = 1, pix_per_split = 0;
   int debug_plain_store = 0;       // timing experiments only: plain stores instead of atomics
+  int rev = 0;                     // 1: pixel splits are handed out back to front (see ConvParams::rev)
   FastDiv divOW, divOH, divCpad, divTJpad;
 };
 

@@ -140,7 +140,7 @@ void conv_wgrad_kernel(const WgradParams p) {
   const int tilesC = (p.Cout + BCO - 1) / BCO;
   const int kt = blockIdx.x / tilesC, ct = blockIdx.x % tilesC;
   const int k0 = kt * BKK, c0 = ct * BCO;
-  const int pbeg = blockIdx.y * p.pix_per_split;
+  const int pbeg = (p.rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y) * p.pix_per_split;
   const int pend = min(pbeg + p.pix_per_split, p.P);
   if (pbeg >= pend) return;
 

@@ -11,8 +11,8 @@ void launch_bn_fwd_train(const void* y, const void* res, void* z, uint8_t* mask,
                          const float* gamma, const float* beta, float* mm, float* mv,
                          float* save_mean, float* save_invstd, float* scale, float* shift,
                          float* ws, int fused_replicas, int P, int C, float eps, float momentum,
-                         int relu, const float* rscale, const float* rshift, int apply, int dt,
-                         hipStream_t s);
+                         int relu, const float* rscale, const float* rshift, int apply, int rev,
+                         int dt, hipStream_t s);
 // Folded inference constants of every BatchNorm layer (descriptor layout: see bn.hip).
 int bn_fold_desc_size();
 void launch_bn_fold(const float* params, const float* state, float* out, const void* descs,
@@ -33,14 +33,17 @@ void launch_bn_bwd_dual(const void* dz, const uint8_t* mask, int P, int C, float
                         const float* gamma1, float* dgamma1, float* dbeta1, void* dy1,
                         const void* y2, const float* mean2, const float* invstd2,
                         const float* gamma2, float* dgamma2, float* dbeta2, void* dy2,
-                        float* tail, int dt, hipStream_t s);
+                        float* tail, int rev, int dt, hipStream_t s);
 void launch_bn_infer(const void* y, const void* res, void* z, const float* gamma,
                      const float* beta, const float* mm, const float* mv, int P, int C, float eps,
                      int relu, int dt, hipStream_t s);
 void launch_bn_bwd(const void* dz, const void* y, const void* z, const uint8_t* mask,
                    const float* mean, const float* invstd, const float* gamma, float* dgamma,
                    float* dbeta, void* dy, void* dres, float* ws, int P, int C,
-                   int pre_replicas, float* tail, int dt, hipStream_t s);
+                   int pre_replicas, float* tail, int rev, int dt, hipStream_t s);
+// `rev`: bit 0 - the reduction sweep, bit 1 - the apply sweep walks the rows back to front (the
+// launch plan alternates directions so that a sweep starts on the rows still in the memory-side
+// cache; `rev` of the forward launch is the apply sweep's direction).
 // `tail` (optional, bn_tail_floats() zeroed floats, shared by launches of one stream): the
 // reduction sweep adds its per-block sums to a few replica rows and its last block derives
 // dgamma / dbeta, so no finalize launch sits between the two sweeps.  The sums then depend on

@@ -75,6 +75,11 @@ def test_conv_fwd_dgrad_wgrad(case):
   assert out.shape[:3] == ref.shape[:3]
   err = (out.float() - ref).abs().max().item()
   assert err <= 0.02 * ref.abs().max().item() + 1e-2, err
+  # pixel tiles handed out back to front (the launch plan's cache-aware direction): same result
+  out_r = torch.full(g.output_shape, float("nan"), dtype=torch.bfloat16, device=dev)
+  native.run_op("conv", dict(g.fwd(x.data_ptr(), wf.data_ptr(), out_r.data_ptr()), rev=1))
+  torch.cuda.synchronize()
+  assert torch.equal(out_r.view(torch.int16), out.view(torch.int16))
   # ---- data gradient (fp32 autograd reference on the same bf16-rounded operands)
   dy = _bf(torch.randn(N, g.OH, g.OW, Cout, generator=gen)).to(dev)
   xr = x.float().requires_grad_(True)
@@ -87,6 +92,11 @@ def test_conv_fwd_dgrad_wgrad(case):
   torch.cuda.synchronize()
   err = (dx.float() - xr.grad).abs().max().item()
   assert err <= 0.02 * xr.grad.abs().max().item() + 1e-2, err
+  dx_r = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=dev)
+  for d in g.dgrad(dy.data_ptr(), wd.data_ptr(), dx_r.data_ptr()):
+    native.run_op("conv", dict(d, rev=1))
+  torch.cuda.synchronize()
+  assert torch.equal(dx_r.view(torch.int16), dx.view(torch.int16))
   # accumulate mode adds to the existing tensor
   dx2 = dx.clone()
   for d in g.dgrad(dy.data_ptr(), wd.data_ptr(), dx2.data_ptr(), accumulate=True):
@@ -98,6 +108,11 @@ def test_conv_fwd_dgrad_wgrad(case):
   native.run_op("wgrad", g.wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr()))
   torch.cuda.synchronize()
   err = (dw - wr.grad).abs().max().item()
+  assert err <= 0.01 * wr.grad.abs().max().item() + 1e-2, err
+  dw_r = torch.zeros(K, K, Cin, Cout, dtype=torch.float32, device=dev)
+  native.run_op("wgrad", dict(g.wgrad(x.data_ptr(), dy.data_ptr(), dw_r.data_ptr()), splits=3, rev=1))
+  torch.cuda.synchronize()
+  err = (dw_r - wr.grad).abs().max().item()
   assert err <= 0.01 * wr.grad.abs().max().item() + 1e-2, err
 
 
@@ -535,6 +550,58 @@ def test_batchnorm_fwd_bwd(C, relu, residual, use_mask):
   torch.cuda.synchronize()
   ref2 = (y.float() - mm) * torch.rsqrt(mv + 1e-5) * gamma + beta
   assert torch.allclose(z2.float(), ref2, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("C,P", [(2048, 3139), (256, 40003), (64, 70001), (8, 300001)])
+def test_batchnorm_sweep_directions(C, P):
+  """The BatchNorm sweeps walk their passes front to back or back to front (`rev`, `rev_reduce`,
+  `rev_apply`: the launch plan picks the end of the tensor that is still cached): several passes
+  with a ragged last one, every direction against the front-to-back launch."""
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator().manual_seed(C + P)
+  y = _bf(torch.randn(P, C, generator=gen) * 2 + 0.5).to(dev)
+  res = _bf(torch.randn(P, C, generator=gen)).to(dev)
+  dz = _bf(torch.randn(P, C, generator=gen)).to(dev)
+  gamma = (torch.rand(C, generator=gen) + 0.5).to(dev)
+  beta = (torch.randn(C, generator=gen) * 0.1).to(dev)
+  ws = torch.zeros(native.ext().bn_workspace_floats(), device=dev)
+  nmask = (P * C // 8 + 3) // 4 * 4
+
+  def run(rev_f, rev_r, rev_a):
+    mm, mv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    saved = torch.zeros(4 * C, device=dev)
+    z = torch.full((P, C), float("nan"), dtype=torch.bfloat16, device=dev)
+    mask = torch.full((nmask,), 0xAA, dtype=torch.uint8, device=dev)
+    native.run_op("bn_fwd_train", dict(
+        y=y.data_ptr(), res=res.data_ptr(), z=z.data_ptr(), mask=mask.data_ptr(),
+        gamma=gamma.data_ptr(), beta=beta.data_ptr(), mm=mm.data_ptr(), mv=mv.data_ptr(),
+        save_mean=saved.data_ptr(), save_invstd=saved.data_ptr() + 4 * C,
+        scale=saved.data_ptr() + 8 * C, shift=saved.data_ptr() + 12 * C, ws=ws.data_ptr(),
+        P=P, C=C, eps=1e-5, momentum=0.9, relu=1, rev=rev_f))
+    dgamma, dbeta = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dy = torch.full((P, C), float("nan"), dtype=torch.bfloat16, device=dev)
+    dres = torch.full((P, C), float("nan"), dtype=torch.bfloat16, device=dev)
+    native.run_op("bn_bwd", dict(
+        dz=dz.data_ptr(), y=y.data_ptr(), z=None, mask=mask.data_ptr(), mean=saved.data_ptr(),
+        invstd=saved.data_ptr() + 4 * C, gamma=gamma.data_ptr(), dgamma=dgamma.data_ptr(),
+        dbeta=dbeta.data_ptr(), dy=dy.data_ptr(), dres=dres.data_ptr(), ws=ws.data_ptr(), P=P, C=C,
+        rev_reduce=rev_r, rev_apply=rev_a))
+    torch.cuda.synchronize()
+    return z, mask[:P * C // 8].clone(), dgamma, dbeta, dy, dres
+
+  z0, m0, dg0, db0, dy0, dr0 = run(0, 0, 0)
+  zr = torch.relu((y.float() - y.float().mean(0)) * torch.rsqrt(y.float().var(0, unbiased=False) + 1e-5)
+                  * gamma + beta + res.float())
+  assert torch.allclose(z0.float(), zr, rtol=2e-2, atol=2e-2)
+  for rev in ((1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 1)):
+    z1, m1, dg1, db1, dy1, dr1 = run(*rev)
+    assert torch.equal(z1.view(torch.int16), z0.view(torch.int16)), rev
+    assert torch.equal(m1, m0), rev
+    assert torch.equal(dr1.view(torch.int16), dr0.view(torch.int16)), rev
+    # the reduction adds its rows in another order: sums agree to rounding, dy to a bf16 ulp
+    assert torch.allclose(dg1, dg0, rtol=1e-4, atol=1e-2) and torch.allclose(db1, db0, rtol=1e-4, atol=1e-2)
+    assert torch.allclose(dy1.float(), dy0.float(), rtol=1e-2, atol=1e-2), rev
 
 
 @pytest.mark.parametrize("N,H,W,C", [(3, 12, 13, 64), (2, 9, 8, 8), (1, 16, 16, 256)])
