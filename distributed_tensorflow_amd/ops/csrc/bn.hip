@@ -246,7 +246,8 @@ __device__ __forceinline__ void fold_columns(const float* __restrict__ ws, int G
   __syncthreads();
 }
 
-template <int DT, bool FOLD>
+// NTM: cache policy, bit 0 - the loads of y / res, bit 1 - the store of z are non-temporal
+template <int DT, bool FOLD, int NTM = 0>
 __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
   const int C = a.C, tpr = C >> 3, rpb = TPB / tpr;
   const int chunk = threadIdx.x % tpr, rowid = threadIdx.x / tpr;
@@ -318,8 +319,8 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
       const int row = prow[u] + rowid;
       valid[u] = p < npass && row < a.P;
       const size_t off = (size_t)row * C + chunk * 8;
-      yq[u] = valid[u] ? ldraw<DT>(a.y, off) : zero_raw<DT>();
-      rq[u] = (valid[u] && a.res) ? ldraw<DT>(a.res, off) : zero_raw<DT>();
+      yq[u] = valid[u] ? ldraw<DT, (NTM & 1) != 0>(a.y, off) : zero_raw<DT>();
+      rq[u] = (valid[u] && a.res) ? ldraw<DT, (NTM & 1) != 0>(a.res, off) : zero_raw<DT>();
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const BnApplyArgs a) {
             f[c] = fmaxf(f[c], 0.f);
           }
         }
-        straw<DT>(a.z, off, f);
+        straw<DT, (NTM & 2) != 0>(a.z, off, f);
       }
       if (a.relu && a.mask && p0 + u < npass && prow0 < a.P) {   // block-uniform condition
         uint32_t w = bits << (8 * (threadIdx.x & 3));
@@ -386,7 +387,7 @@ struct BnBwdArgs {
 
 constexpr int TAIL_REPLICAS = 8;
 
-template <int DT, int NB, bool TAIL = false>
+template <int DT, int NB, bool TAIL = false, int NTM = 0>
 __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
   const int C = a.C, tpr = C >> 3, rpb = TPB / tpr;
   const int chunk = threadIdx.x % tpr, rowid = threadIdx.x / tpr;
@@ -443,22 +444,22 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const size_t off = (size_t)(row + u * step) * C + chunk * 8;
-      gv[u] = ldraw<DT>(a.dz, off);
-      yq[u] = ldraw<DT>(a.y, off);
-      zq[u] = mode == 1 ? ldraw<DT>(a.z, off) : zero_raw<DT>();
+      gv[u] = ldraw<DT, (NTM & 1) != 0>(a.dz, off);
+      yq[u] = ldraw<DT, (NTM & 1) != 0>(a.y, off);
+      zq[u] = mode == 1 ? ldraw<DT, (NTM & 1) != 0>(a.z, off) : zero_raw<DT>();
       bits[u] = mode == 2 ? a.mask[(size_t)(row + u * step) * tpr + chunk] : 0u;
-      y2q[u] = NB == 2 ? ldraw<DT>(a.y2, off) : zero_raw<DT>();
+      y2q[u] = NB == 2 ? ldraw<DT, (NTM & 1) != 0>(a.y2, off) : zero_raw<DT>();
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) accumulate(gv[u], yq[u], zq[u], bits[u], y2q[u]);
   }
   for (; p < np; ++p, row += step) {
     const size_t off = (size_t)row * C + chunk * 8;
-    const Raw8<DT> gv = ldraw<DT>(a.dz, off);
-    const Raw8<DT> yq = ldraw<DT>(a.y, off);
-    const Raw8<DT> zq = mode == 1 ? ldraw<DT>(a.z, off) : zero_raw<DT>();
+    const Raw8<DT> gv = ldraw<DT, (NTM & 1) != 0>(a.dz, off);
+    const Raw8<DT> yq = ldraw<DT, (NTM & 1) != 0>(a.y, off);
+    const Raw8<DT> zq = mode == 1 ? ldraw<DT, (NTM & 1) != 0>(a.z, off) : zero_raw<DT>();
     const uint32_t bits = mode == 2 ? a.mask[(size_t)row * tpr + chunk] : 0u;
-    const Raw8<DT> y2q = NB == 2 ? ldraw<DT>(a.y2, off) : zero_raw<DT>();
+    const Raw8<DT> y2q = NB == 2 ? ldraw<DT, (NTM & 1) != 0>(a.y2, off) : zero_raw<DT>();
     accumulate(gv, yq, zq, bits, y2q);
   }
   const size_t wrow = (size_t)(TAIL ? blockIdx.x % TAIL_REPLICAS : blockIdx.x) * 2 * C;
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(FIN_TPB) void bn_bwd_finalize_kernel(const BnBwdArg
 // FOLD: `ws` holds G replica rows of [sum g | sum g*y] (left by the data-gradient epilogues) of
 // a narrow layer; every block derives dbeta / dgamma itself (block 0 stores them into the
 // gradient buffer) instead of waiting for a finalize launch.
-template <int DT, bool FOLD, int NB = 1>
+template <int DT, bool FOLD, int NB = 1, int NTM = 0>
 __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   const int C = a.C, tpr = C >> 3, rpb = TPB / tpr;
   const int chunk = threadIdx.x % tpr, rowid = threadIdx.x / tpr;
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
       const float xhat = (yv[c] - mean[c]) * invstd[c];
       o[c] = scale[c] * (g[c] - c1[c] - xhat * c2[c]);
     }
-    straw<DT>(a.dy, off, o);
+    straw<DT, (NTM & 2) != 0>(a.dy, off, o);
     if constexpr (NB == 2) {
       float y2v[8], o2[8];
       unpack8<DT>(y2q, y2v);
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
         const float xhat = (y2v[c] - mean2[c]) * invstd2[c];
         o2[c] = scale2[c] * (g[c] - c12[c] - xhat * c22[c]);
       }
-      straw<DT>(a.dy2, off, o2);
+      straw<DT, (NTM & 2) != 0>(a.dy2, off, o2);
     }
   };
   const int stride = gridDim.x * rpb;
@@ -627,22 +628,22 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       off[u] = (size_t)(row + u * step) * C + chunk * 8;
-      gv[u] = ldraw<DT>(a.dz, off[u]);
-      yq[u] = ldraw<DT>(a.y, off[u]);
-      zq[u] = mode == 1 ? ldraw<DT>(a.z, off[u]) : zero_raw<DT>();
+      gv[u] = ldraw<DT, (NTM & 1) != 0>(a.dz, off[u]);
+      yq[u] = ldraw<DT, (NTM & 1) != 0>(a.y, off[u]);
+      zq[u] = mode == 1 ? ldraw<DT, (NTM & 1) != 0>(a.z, off[u]) : zero_raw<DT>();
       bits[u] = mode == 2 ? a.mask[(size_t)(row + u * step) * tpr + chunk] : 0u;
-      y2q[u] = NB == 2 ? ldraw<DT>(a.y2, off[u]) : zero_raw<DT>();
+      y2q[u] = NB == 2 ? ldraw<DT, (NTM & 1) != 0>(a.y2, off[u]) : zero_raw<DT>();
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) finish(gv[u], yq[u], zq[u], bits[u], off[u], y2q[u]);
   }
   for (; p < np; ++p, row += step) {
     const size_t off = (size_t)row * C + chunk * 8;
-    const Raw8<DT> gv = ldraw<DT>(a.dz, off);
-    const Raw8<DT> yq = ldraw<DT>(a.y, off);
-    const Raw8<DT> zq = mode == 1 ? ldraw<DT>(a.z, off) : zero_raw<DT>();
+    const Raw8<DT> gv = ldraw<DT, (NTM & 1) != 0>(a.dz, off);
+    const Raw8<DT> yq = ldraw<DT, (NTM & 1) != 0>(a.y, off);
+    const Raw8<DT> zq = mode == 1 ? ldraw<DT, (NTM & 1) != 0>(a.z, off) : zero_raw<DT>();
     const uint32_t bits = mode == 2 ? a.mask[(size_t)row * tpr + chunk] : 0u;
-    const Raw8<DT> y2q = NB == 2 ? ldraw<DT>(a.y2, off) : zero_raw<DT>();
+    const Raw8<DT> y2q = NB == 2 ? ldraw<DT, (NTM & 1) != 0>(a.y2, off) : zero_raw<DT>();
     finish(gv, yq, zq, bits, off, y2q);
   }
 }
@@ -988,6 +989,25 @@ void launch_bn_fold(const float* params, const float* state, float* out, const v
                      reinterpret_cast<const BnFoldDesc*>(descs));
 }
 
+// Cache policy of a sweep over tensors of `bytes` each (DTF_NT_SWITCH): a tensor that does not
+// fit the 256 MB memory-side cache next to its companions streams through with non-temporal
+// accesses; smaller ones stay cacheable so that the next launch finds them.  `which` selects the
+// bits of DTF_BN_NT (default 0x3f): 0 forward apply, 1 backward reduction, 2 backward apply; two
+// bits each, loads / stores.
+static int nt_mode(int which, size_t bytes) {
+  static const size_t threshold = [] {
+    const char* e = std::getenv("DTF_BN_NT_BYTES");
+    return e ? (size_t)std::atoll(e) : (size_t)90 << 20;
+  }();
+  static const int mask = [] {
+    const char* e = std::getenv("DTF_BN_NT");
+    return e ? (int)std::strtol(e, nullptr, 0) : 0x3f;
+  }();
+  return bytes >= threshold ? (mask >> (2 * which)) & 3 : 0;
+}
+
+static size_t elem_bytes(int dt) { return dt == DT_F32 ? 4 : 2; }
+
 size_t bn_workspace_floats() { return (size_t)MAX_PARTIAL_BLOCKS * 2 * 2048; }
 
 void launch_bn_fwd_train(const void* y, const void* res, void* z, uint8_t* mask,
@@ -1021,8 +1041,9 @@ void launch_bn_fwd_train(const void* y, const void* res, void* z, uint8_t* mask,
                    P, C, eps, momentum};
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, f);
   if (apply) {    // apply == 0: statistics only, a later layer normalises this tensor on the fly
-    DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_apply_kernel<DT, false>), dim3(rows_grid(P, C)),
-                                         dim3(TPB), 0, s, a));
+    const int ntm = nt_mode(0, (size_t)P * C * elem_bytes(dt));
+    DTF_NT_SWITCH(ntm, DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_apply_kernel<DT, false, NTM>),
+                                                            dim3(rows_grid(P, C)), dim3(TPB), 0, s, a)));
   }
 }
 
@@ -1160,12 +1181,16 @@ void launch_bn_bwd(const void* dz, const void* y, const void* z, const uint8_t* 
                                          dim3(TPB), 0, s, a));
     return;
   }
+  const size_t bytes = (size_t)P * C * elem_bytes(dt);
   if (pre_replicas == 0) {
-    DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_reduce_kernel<DT, 1>), dim3(G), dim3(TPB), 0, s, a));
+    const int ntr = nt_mode(1, bytes);
+    DTF_NT_SWITCH(ntr, DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_reduce_kernel<DT, 1, false, NTM>),
+                                                            dim3(G), dim3(TPB), 0, s, a)));
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, a);
-  DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, false>), dim3(rows_grid(P, C)),
-                                       dim3(TPB), 0, s, a));
+  const int nta = nt_mode(2, bytes);
+  DTF_NT_SWITCH(nta, DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, false, 1, NTM>),
+                                                          dim3(rows_grid(P, C)), dim3(TPB), 0, s, a)));
 }
 
 // Backward of two BatchNorm layers that receive the same gradient g = dz gated by `mask`
@@ -1194,11 +1219,14 @@ void launch_bn_bwd_dual(const void* dz, const uint8_t* mask, int P, int C, float
                                          dim3(TPB), 0, s, a));
     return;
   }
-  DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_reduce_kernel<DT, 2>), dim3(G), dim3(TPB), 0, s, a));
+  const size_t bytes = (size_t)P * C * elem_bytes(dt);
+  const int ntr = nt_mode(1, bytes), nta = nt_mode(2, bytes);
+  DTF_NT_SWITCH(ntr, DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_reduce_kernel<DT, 2, false, NTM>),
+                                                          dim3(G), dim3(TPB), 0, s, a)));
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, a);
   BnBwdArgs b = a;                   // the finalize kernel reads the first layer's fields
   b.ws = ws2; b.dgamma = dgamma2; b.dbeta = dbeta2; b.mean = mean2; b.invstd = invstd2;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_TPB), 0, s, b);
-  DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, false, 2>), dim3(rows_grid(P, C)),
-                                       dim3(TPB), 0, s, a));
+  DTF_NT_SWITCH(nta, DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, false, 2, NTM>),
+                                                          dim3(rows_grid(P, C)), dim3(TPB), 0, s, a)));
 }

@@ -552,11 +552,13 @@ def test_batchnorm_fwd_bwd(C, relu, residual, use_mask):
   assert torch.allclose(z2.float(), ref2, rtol=2e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("C,P", [(2048, 3139), (256, 40003), (64, 70001), (8, 300001)])
+@pytest.mark.parametrize("C,P", [(2048, 3139), (256, 40003), (64, 70001), (8, 300001),
+                                 (256, 190001)])
 def test_batchnorm_sweep_directions(C, P):
   """The BatchNorm sweeps walk their passes front to back or back to front (`rev`, `rev_reduce`,
   `rev_apply`: the launch plan picks the end of the tensor that is still cached): several passes
-  with a ragged last one, every direction against the front-to-back launch."""
+  with a ragged last one, every direction against the front-to-back launch.  The last case is a
+  97 MB tensor: above 90 MB the sweeps switch to non-temporal loads and stores."""
   native = _native()
   dev = torch.device("cuda")
   gen = torch.Generator().manual_seed(C + P)
