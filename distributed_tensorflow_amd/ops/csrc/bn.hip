@@ -1033,8 +1033,9 @@ void launch_bn_fwd_train(const void* y, const void* res, void* z, uint8_t* mask,
                 rev};
   if (apply && fold_ok && fused_replicas > 0 && fused_replicas * 2 * C <= 16384 &&
       C <= FOLD_MAX_C) {
-    DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_apply_kernel<DT, true>), dim3(rows_grid(P, C)),
-                                         dim3(TPB), 0, s, a));
+    const int ntm = nt_mode(0, (size_t)P * C * elem_bytes(dt));
+    DTF_NT_SWITCH(ntm, DTF_DT_SWITCH(dt, hipLaunchKernelGGL((bn_apply_kernel<DT, true, NTM>),
+                                                            dim3(rows_grid(P, C)), dim3(TPB), 0, s, a)));
     return;
   }
   BnFinalizeArgs f{ws, G, gamma, beta, mm, mv, save_mean, save_invstd, scale, shift,
