@@ -171,6 +171,48 @@ def _decode_for_crop(image_buffer: bytes, rng, bbox: np.ndarray, out_h: int, out
   return img, (y, x, h, w)
 
 
+def _jpeg_region_decoder():
+  """`_dtf_data` when its JPEG region decoder can be used (libjpeg-turbo found at run time,
+  `DTF_JPEG_REGION` not 0), else None."""
+  if os.environ.get("DTF_JPEG_REGION", "1") == "0":
+    return None
+  from . import native_loader  # pylint: disable=import-outside-toplevel
+  if not native_loader.available():
+    return None
+  ext = native_loader.ext()
+  return ext if getattr(ext, "jpeg_region_available", lambda: False)() else None
+
+
+def _decode_region_for_crop(ext, image_buffer: bytes, rng, bbox: np.ndarray, out_h: int, out_w: int):
+  """Training decode through the region decoder (`ops/csrc/jpeg_region.h`): the distorted crop
+  box is sampled from the header's dimensions, then only the box's rows and MCU-aligned columns
+  are decoded - what the reference's `tf.image.decode_and_crop_jpeg` does
+  (`imagenet_preprocessing.py:259-323`) - at 1/2, 1/4 or 1/8 scale when the box still has the
+  output resolution there.  Returns (uint8 pixels, box inside them) like `_decode_for_crop`, or
+  None when the file is not a plain JPEG (CMYK, PNG content, damaged): the caller then decodes
+  with PIL, drawing the same random numbers again."""
+  hdr = ext.jpeg_header(image_buffer)
+  if hdr is None or hdr[2] not in (1, 3):
+    return None
+  height, width = int(hdr[0]), int(hdr[1])
+  gen = getattr(rng, "bit_generator", None)
+  state = gen.state if gen is not None else None
+  y, x, h, w = sample_distorted_bounding_box(height, width, bbox, rng)
+  denom = 1
+  if _jpeg_draft_enabled():
+    while denom < 8 and h >= 2 * denom * out_h and w >= 2 * denom * out_w:
+      denom *= 2
+  ys, xs, hs, ws = y // denom, x // denom, max(1, h // denom), max(1, w // denom)
+  res = ext.jpeg_decode_region(image_buffer, ys, xs, hs, ws, denom)
+  if res is None:
+    if gen is not None:
+      gen.state = state
+    return None
+  pixels, y0, x0, _sh, _sw = res
+  by, bx = ys - y0, xs - x0
+  return pixels, (by, bx, min(hs, pixels.shape[0] - by), min(ws, pixels.shape[1] - bx))
+
+
 def _decode_crop_and_flip(image_buffer: bytes, bbox: np.ndarray, rng):
   """Random distorted-box crop + random horizontal flip. Returns a PIL image."""
   from PIL import Image  # pylint: disable=import-outside-toplevel
@@ -229,14 +271,21 @@ def preprocess_image(image_buffer: bytes, bbox: np.ndarray, output_height: int,
   preserving resize to a short side of 256 and a central crop (`imagenet_preprocessing.py:503-537`);
   then the channel means are subtracted.  With the native input module the crop, the resize
   (TensorFlow's legacy bilinear rule, which the reference's `_resize_image` uses), the flip and
-  the mean subtraction are one C++ pass over the decoded image; otherwise PIL does the resize.
+  the mean subtraction are one C++ pass over the decoded image, and training JPEGs are decoded
+  inside their crop box only; otherwise PIL decodes and resizes.
   """
   rng = rng or np.random.default_rng()
   fast = _native_resize() if num_channels == 3 else None
   if fast is not None:
     if is_training:
-      img, (y, x, h, w) = _decode_for_crop(image_buffer, rng, bbox, output_height, output_width)
-      pixels = np.asarray(img)                             # uint8 [H, W, 3]
+      region = _jpeg_region_decoder()
+      got = _decode_region_for_crop(region, image_buffer, rng, bbox, output_height, output_width) \
+          if region is not None else None
+      if got is not None:
+        pixels, (y, x, h, w) = got                         # uint8 [rows, cols, 3] around the box
+      else:
+        img, (y, x, h, w) = _decode_for_crop(image_buffer, rng, bbox, output_height, output_width)
+        pixels = np.asarray(img)                           # uint8 [H, W, 3]
       flip = bool(rng.random() < 0.5)
       return fast(pixels, y, x, h, w, output_height, output_width, 0, 0, output_height,
                   output_width, flip, list(_CHANNEL_MEANS))

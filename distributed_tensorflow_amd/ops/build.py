@@ -61,9 +61,9 @@ def build_data(force: bool = False, verbose: bool = True) -> str:
   """Host-only module `_dtf_data` (input pipeline): plain g++, no GPU code."""
   src = os.path.join(CSRC, "data_loader.cpp")
   target = data_so_path()
-  if force or _stale(target, [src]):
+  if force or _stale(target, [src, os.path.join(CSRC, "jpeg_region.h")]):
     cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-fvisibility=hidden",
-           src, "-o", target] + _includes()
+           src, "-o", target, "-ldl"] + _includes()
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
       raise RuntimeError("g++ failed for data_loader.cpp:\n%s\n%s" % (r.stdout, r.stderr))

@@ -11,6 +11,7 @@
 //
 // No GPU code here; the buffers these functions fill are pinned host tensors that the device
 // prefetcher copies on its own stream.
+#include "jpeg_region.h"
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -398,6 +399,37 @@ PYBIND11_MODULE(_dtf_data, m) {
     return masked_crc32c(reinterpret_cast<const uint8_t*>(s.data()), s.size());
   });
   m.def("tfrecord_read_all", &tfrecord_read_all, py::arg("path"), py::arg("verify") = true);
+  // Region decode of JPEG files (jpeg_region.h).  `jpeg_header` -> (height, width, components) or
+  // None; `jpeg_decode_region(bytes, y, x, h, w, denom)` -> (uint8 [rows, cols, 3], y0, x0,
+  // image height, image width) in the coordinates of the image scaled by 1 / denom, or None when
+  // the file needs the general decoder.
+  m.def("jpeg_region_available", []() { return jpeg_region::available(); });
+  m.def("jpeg_region_status", []() {
+    const jpeg_region::Api& a = jpeg_region::api();
+    return py::make_tuple(a.ok, a.version, (int)a.struct_size, a.why);
+  });
+  m.def("jpeg_header", [](py::bytes b) -> py::object {
+    char* data; Py_ssize_t n;
+    if (PyBytes_AsStringAndSize(b.ptr(), &data, &n)) throw py::error_already_set();
+    int h = 0, w = 0, comps = 0;
+    if (!jpeg_region::header(reinterpret_cast<const uint8_t*>(data), (size_t)n, &h, &w, &comps))
+      return py::none();
+    return py::make_tuple(h, w, comps);
+  });
+  m.def("jpeg_decode_region", [](py::bytes b, int y, int x, int h, int w, int denom) -> py::object {
+    char* data; Py_ssize_t n;
+    if (PyBytes_AsStringAndSize(b.ptr(), &data, &n)) throw py::error_already_set();
+    jpeg_region::Region r;
+    bool ok;
+    {
+      py::gil_scoped_release nogil;
+      ok = jpeg_region::decode(reinterpret_cast<const uint8_t*>(data), (size_t)n, y, x, h, w, denom, &r);
+    }
+    if (!ok) return py::none();
+    py::array_t<uint8_t> out({r.rows, r.cols, 3});
+    std::memcpy(out.mutable_data(), r.pixels.data(), r.pixels.size());
+    return py::make_tuple(out, r.y0, r.x0, r.image_h, r.image_w);
+  }, py::arg("data"), py::arg("y"), py::arg("x"), py::arg("h"), py::arg("w"), py::arg("denom") = 1);
   m.def("crop_resize_bilinear", &crop_resize_bilinear, py::arg("image"), py::arg("y"), py::arg("x"),
         py::arg("h"), py::arg("w"), py::arg("resized_h"), py::arg("resized_w"), py::arg("top"),
         py::arg("left"), py::arg("out_h"), py::arg("out_w"), py::arg("flip") = false,

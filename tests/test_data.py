@@ -366,3 +366,58 @@ def test_training_decode_uses_scaled_jpeg_decoding_for_large_photographs(monkeyp
   b = ip.preprocess_image(raw, whole, 224, 224, 3, True, FullCrop())
   assert a.shape == b.shape == (224, 224, 3)
   assert np.abs(a - b).mean() < 6.0            # of 255: same content, different resampling
+
+
+def test_training_decode_inside_the_crop_box_matches_the_full_decode(monkeypatch):
+  """The region decoder (`ops/csrc/jpeg_region.h`: only the crop box's rows and MCU-aligned
+  columns are decoded, as `tf.image.decode_and_crop_jpeg` does for the reference) yields the
+  pixels of a full PIL decode inside the box, so a training sample is the same either way;
+  files it does not handle (here: PNG content) fall back to PIL with the same random numbers."""
+  import io
+  import numpy as np
+  from PIL import Image
+  from distributed_tensorflow_amd.data import imagenet_preprocessing as ip, native_loader
+  if not native_loader.available() or not native_loader.ext().jpeg_region_available():
+    pytest.skip("no libjpeg-turbo with partial decoding on this machine: %s"
+                % (native_loader.ext().jpeg_region_status(),) if native_loader.available() else "")
+  ext = native_loader.ext()
+  rng0 = np.random.default_rng(3)
+  small = rng0.integers(0, 256, size=(48, 64, 3), dtype=np.uint8)
+  picture = Image.fromarray(small).resize((500, 375), Image.BICUBIC)
+  buf = io.BytesIO()
+  picture.save(buf, format="JPEG", quality=90)
+  raw = buf.getvalue()
+  assert ext.jpeg_header(raw) == (375, 500, 3)
+  full = np.asarray(Image.open(io.BytesIO(raw)).convert("RGB"))
+  for (y, x, h, w) in [(0, 0, 375, 500), (37, 101, 200, 250), (300, 434, 75, 66), (5, 9, 17, 33)]:
+    pix, y0, x0, ih, iw = ext.jpeg_decode_region(raw, y, x, h, w, 1)
+    assert (ih, iw) == (375, 500) and y0 == y and x0 <= x and x0 + pix.shape[1] >= x + w
+    box = pix[:, x - x0:x - x0 + w].astype(int)
+    want = full[y:y + h, x:x + w].astype(int)
+    # identical except next to a cut that is not on an MCU boundary (chroma upsampling there
+    # sees no neighbour): within a few levels in the outermost columns
+    assert np.array_equal(box[:, 1:-1], want[:, 1:-1]) and np.abs(box - want).max() <= 24
+  # half scale: the scaled image's size and a picture close to the full decode reduced by two
+  pix, y0, x0, ih, iw = ext.jpeg_decode_region(raw, 10, 24, 100, 120, 2)
+  assert (ih, iw) == (188, 250) and pix.shape[0] == 100
+  ref = np.asarray(picture.resize((250, 188), Image.BILINEAR)).astype(int)
+  assert np.abs(pix[:, 24 - x0:24 - x0 + 120].astype(int) - ref[10:110, 24:144]).mean() < 8.0
+  # the whole training sample: same random numbers, region decoder against PIL
+  bbox = np.array([[0.2, 0.1, 0.9, 0.8]], np.float32)
+  for seed in range(6):
+    a = ip.preprocess_image(raw, bbox, 224, 224, 3, True, np.random.default_rng(seed))
+    monkeypatch.setenv("DTF_JPEG_REGION", "0")
+    b = ip.preprocess_image(raw, bbox, 224, 224, 3, True, np.random.default_rng(seed))
+    monkeypatch.delenv("DTF_JPEG_REGION")
+    assert a.shape == b.shape == (224, 224, 3)
+    assert np.abs(a - b).max() <= 24.0 and np.abs(a - b).mean() < 0.05
+  # not a JPEG: the header probe declines, PIL decodes
+  png = io.BytesIO()
+  picture.save(png, format="PNG")
+  assert ext.jpeg_header(png.getvalue()) is None
+  c = ip.preprocess_image(png.getvalue(), bbox, 224, 224, 3, True, np.random.default_rng(1))
+  monkeypatch.setenv("DTF_JPEG_REGION", "0")
+  d = ip.preprocess_image(png.getvalue(), bbox, 224, 224, 3, True, np.random.default_rng(1))
+  assert np.array_equal(c, d)
+  # a truncated file does not crash the worker: the decoder reports failure or pads like PIL
+  assert ext.jpeg_decode_region(raw[:200], 0, 0, 10, 10, 1) is None
