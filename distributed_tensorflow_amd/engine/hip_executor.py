@@ -565,12 +565,41 @@ class HipExecutor:
     return [(desc.get("in"), nin), (desc.get("out"), nout), (desc.get("addend"), nout),
             (desc.get("stats_y"), nout)]
 
+  def _lane_tile(self, desc: Dict) -> Dict:
+    """Tile of a weight gradient that runs on the side lane of a large step.
+
+    The tile table is measured on kernels running alone, where small tiles (128x64, 64x128,
+    64x64) or four wave groups often win by a few percent.  Next to the main lane's memory-bound
+    kernels the 128x128 tile with two wave groups is the better neighbour - half the blocks,
+    half the operand traffic through L2 per multiply-add: ResNet-50 bs256 20.81 -> 20.44 ms per
+    step with the split counts unchanged (doubling them with the tile: 20.74; the 256x128
+    tile: 20.52; `scripts/debug/wgrad_force_cfg.sh`).  `DTF_WGRAD_LANE_TILE=0` keeps the table."""
+    if (os.environ.get("DTF_WGRAD_LANE_TILE", "1") == "0" or self.dt not in (0, 1)
+        or not getattr(self, "_large_step", False) or desc.get("batch") is not None
+        or desc["TI"] * desc["TJ"] * desc["Ctap"] < 256 or desc["Cout"] < 128):
+      return desc
+    cfg = int(desc.get("cfg", 0))
+    tile, groups = cfg % 16, 1 << ((cfg % 64) // 16)
+    if tile in (1, 2, 3) or (tile == 0 and groups == 4):
+      desc = dict(desc, cfg=16)          # 128x128, two wave groups, two-stage ring
+    mul = os.environ.get("DTF_WGRAD_LANE_SPLITS_MUL")            # A/B runs: split counts scaled
+    if mul:
+      desc = dict(desc, splits=max(1, int(round(desc.get("splits", 1) * float(mul)))))
+    remap = os.environ.get("DTF_WGRAD_LANE_MAP")     # A/B runs: "16:24,0:24" = tile -> tile
+    if remap:
+      table = dict(e.split(":") for e in remap.split(","))
+      if str(desc.get("cfg", 0)) in table:
+        desc = dict(desc, cfg=int(table[str(desc.get("cfg", 0))]))
+    return desc
+
   def _add(self, plan, kind: str, desc: Dict, name: str, lane: int = 0):
     """plan.add with the measured tile configuration of this shape, when one is known."""
     if kind in ("conv", "wgrad"):
       desc = autotune.apply(kind, desc)
     if kind == "wgrad" and self.deterministic:
       desc = dict(desc, splits=1)
+    if kind == "wgrad" and lane == 1:
+      desc = self._lane_tile(desc)
     if kind == "conv" and "rev" not in desc and desc.get("pro_sums") is None \
         and desc.get("bpro_sums") is None:
       desc = dict(desc, rev=self._sweep_dir(self._conv_tensors(desc)))
@@ -882,6 +911,7 @@ class HipExecutor:
       # delays the weight gradients and was slightly slower (ResNet-50 bs256: 22.75 -> 22.9 ms).
       act_bytes = sum(t.numel() * t.element_size() for t in acts.values())
       self.wgrad_group = 4 if act_bytes < (2 << 30) else 1
+    self._large_step = sum(t.numel() * t.element_size() for t in acts.values()) >= (2 << 30)
     plan.add("memset", dict(ptr=self.store.grads.data_ptr(),
                             nbytes=self.store.grads.numel() * 4), "zero_grads")
     first_conv = next(o for o in spec.ops if o.kind == "conv")
