@@ -600,6 +600,13 @@ class HipExecutor:
       desc = dict(desc, splits=1)
     if kind == "wgrad" and lane == 1:
       desc = self._lane_tile(desc)
+    if kind == "conv" and plan is getattr(self, "bwd_plan", None) and os.environ.get("DTF_DGRAD_LANE_MAP"):
+      table = dict(e.split(":") for e in os.environ["DTF_DGRAD_LANE_MAP"].split(","))   # A/B runs
+      if str(desc.get("cfg", 0)) in table:
+        desc = dict(desc, cfg=int(table[str(desc.get("cfg", 0))]))
+    if os.environ.get("DTF_PRINT_CFGS") and kind in ("conv", "wgrad"):
+      logging.warning("cfg %s %s lane %d cfg %s splits %s", kind, name, lane, desc.get("cfg"),
+                      desc.get("splits"))
     if kind == "conv" and "rev" not in desc and desc.get("pro_sums") is None \
         and desc.get("bpro_sums") is None:
       desc = dict(desc, rev=self._sweep_dir(self._conv_tensors(desc)))
