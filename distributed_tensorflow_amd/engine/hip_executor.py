@@ -573,11 +573,17 @@ class HipExecutor:
     kernels the 128x128 tile with two wave groups is the better neighbour - half the blocks,
     half the operand traffic through L2 per multiply-add: ResNet-50 bs256 20.81 -> 20.44 ms per
     step with the split counts unchanged (doubling them with the tile: 20.74; the 256x128
-    tile: 20.52; `scripts/debug/wgrad_force_cfg.sh`).  `DTF_WGRAD_LANE_TILE=0` keeps the table."""
+    tile: 20.52; `scripts/debug/wgrad_force_cfg.sh`).  That rule is the fallback: shapes found in
+    `ops/tuned_gfx950_lane.json` use the tile and split count that minimised the time of whole
+    training steps (`scripts/tune_lane_wgrad.py`).  `DTF_WGRAD_LANE_TILE=0` keeps the table."""
     if (os.environ.get("DTF_WGRAD_LANE_TILE", "1") == "0" or self.dt not in (0, 1)
         or not getattr(self, "_large_step", False) or desc.get("batch") is not None
         or desc["TI"] * desc["TJ"] * desc["Ctap"] < 256 or desc["Cout"] < 128):
       return desc
+    self.__dict__.setdefault("lane_wgrads", []).append(dict(desc))     # for the in-step tuner
+    hit = autotune.lane_lookup(desc)
+    if hit is not None:                  # measured in whole training steps
+      return dict(desc, cfg=hit["cfg"], splits=hit.get("splits", desc.get("splits", 1)))
     cfg = int(desc.get("cfg", 0))
     tile, groups = cfg % 16, 1 << ((cfg % 64) // 16)
     if tile in (1, 2, 3) or (tile == 0 and groups == 4):

@@ -234,3 +234,32 @@ def save(path: Optional[str] = None):
   with open(path, "w") as f:
     json.dump(_load(), f, indent=0, sort_keys=True)
   _dirty = False
+
+
+# ---- weight gradients next to the main lane ------------------------------------------------
+# The table above is measured on kernels running alone.  A weight gradient on the side lane of a
+# large step runs next to the main lane's memory-bound kernels, where another tile can be the
+# better neighbour (fewer blocks, less operand traffic through L2).  `tuned_gfx950_lane.json`
+# holds, per weight-gradient signature, the choice that minimised the *step* time
+# (`scripts/tune_lane_wgrad.py`: coordinate search over shape classes, whole training steps
+# timed); `LANE_OVERRIDE` lets that search try candidates without touching the file.
+LANE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950_lane.json")
+LANE_OVERRIDE: Dict[str, Dict[str, int]] = {}
+_lane_cache: Optional[Dict[str, Dict[str, int]]] = None
+
+
+def lane_lookup(desc: Dict) -> Optional[Dict[str, int]]:
+  """In-step choice {cfg, splits} for a side-lane weight gradient, or None."""
+  global _lane_cache
+  sig = signature("wgrad", desc)
+  if sig in LANE_OVERRIDE:
+    return LANE_OVERRIDE[sig]
+  if _lane_cache is None:
+    _lane_cache = {}
+    path = os.environ.get("DTF_AUTOTUNE_LANE_CACHE") or LANE_PATH
+    if (os.environ.get("DTF_AUTOTUNE_IGNORE_CACHE", "0") != "1"
+        and os.environ.get("DTF_AUTOTUNE_IGNORE_LANE", "0") != "1" and os.path.exists(path)):
+      with open(path) as f:
+        _lane_cache = json.load(f)
+  return _lane_cache.get(sig)
+

@@ -1,4 +1,17 @@
 #!/bin/bash
-run() { printf "%-60s" "$*"; env "$@" timeout -k 10 120 python bench.py --model resnet56 --batch 128 --steps 300 --warmup 50 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"; }
-run DTF_X=0 && run DTF_BN_GRID_CAP=256 && run DTF_BN_GRID_CAP=1024 && run DTF_BN_GRID_CAP=128 && run DTF_WGRAD_GROUP=3 && run DTF_BWD_STATS_SMALL_BYTES=0
-for i in 1 2; do printf "resnet50 "; timeout -k 10 120 python bench.py --steps 40 --warmup 10 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"; done
+# ResNet-56 bs128: launch mode / weight-gradient grouping / lane matrix (ms per step).
+run() {
+  echo "== $*"
+  env "$@" timeout -k 10 120 python bench.py --model resnet56 --batch 128 --steps 300 --warmup 50 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['config']['launch'])" || exit 1
+}
+run DTF_X=1
+run DTF_HIP_GRAPH=1
+run DTF_HIP_GRAPH=0
+run DTF_WGRAD_GROUP=2
+run DTF_WGRAD_GROUP=8
+run DTF_WGRAD_GROUP=16
+run DTF_WGRAD_BATCH=1
+run DTF_WGRAD_BATCH=1 DTF_WGRAD_GROUP=9
+run DTF_WGRAD_STREAM=0
+run DTF_SWEEP_ORDER=0
+run DTF_X=1
