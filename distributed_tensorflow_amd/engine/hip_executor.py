@@ -565,6 +565,23 @@ class HipExecutor:
     return [(desc.get("in"), nin), (desc.get("out"), nout), (desc.get("addend"), nout),
             (desc.get("stats_y"), nout)]
 
+  def _in_step_choice(self, plan, kind: str, desc: Dict, lane: int) -> Dict:
+    """Tile (and split count) of a training-step launch: the entry of the in-step table
+    (`ops/tuned_gfx950_step.json`, choices that minimised the time of whole training steps,
+    `scripts/tune_in_step.py`) when there is one, else the stand-alone table's choice - for
+    weight gradients on the side lane after the neighbour rule of `_lane_tile`."""
+    if plan is getattr(self, "eval_plan", None) or desc.get("pro_sums") is not None \
+        or desc.get("bpro_sums") is not None:
+      return desc
+    self.__dict__.setdefault("step_launches", []).append((kind, lane, dict(desc)))
+    hit = autotune.step_lookup(kind, desc, lane)
+    if hit is not None:
+      out = dict(desc, cfg=hit["cfg"])
+      if kind == "wgrad" and "splits" in hit:
+        out["splits"] = hit["splits"]
+      return out
+    return self._lane_tile(desc) if kind == "wgrad" and lane == 1 else desc
+
   def _lane_tile(self, desc: Dict) -> Dict:
     """Tile of a weight gradient that runs on the side lane of a large step.
 
@@ -573,17 +590,12 @@ class HipExecutor:
     kernels the 128x128 tile with two wave groups is the better neighbour - half the blocks,
     half the operand traffic through L2 per multiply-add: ResNet-50 bs256 20.81 -> 20.44 ms per
     step with the split counts unchanged (doubling them with the tile: 20.74; the 256x128
-    tile: 20.52; `scripts/debug/wgrad_force_cfg.sh`).  That rule is the fallback: shapes found in
-    `ops/tuned_gfx950_lane.json` use the tile and split count that minimised the time of whole
-    training steps (`scripts/tune_lane_wgrad.py`).  `DTF_WGRAD_LANE_TILE=0` keeps the table."""
+    tile: 20.52; `scripts/debug/wgrad_force_cfg.sh`).  Launches found in the in-step table
+    (`_in_step_choice`) bypass the rule.  `DTF_WGRAD_LANE_TILE=0` keeps the table."""
     if (os.environ.get("DTF_WGRAD_LANE_TILE", "1") == "0" or self.dt not in (0, 1)
         or not getattr(self, "_large_step", False) or desc.get("batch") is not None
         or desc["TI"] * desc["TJ"] * desc["Ctap"] < 256 or desc["Cout"] < 128):
       return desc
-    self.__dict__.setdefault("lane_wgrads", []).append(dict(desc))     # for the in-step tuner
-    hit = autotune.lane_lookup(desc)
-    if hit is not None:                  # measured in whole training steps
-      return dict(desc, cfg=hit["cfg"], splits=hit.get("splits", desc.get("splits", 1)))
     cfg = int(desc.get("cfg", 0))
     tile, groups = cfg % 16, 1 << ((cfg % 64) // 16)
     if tile in (1, 2, 3) or (tile == 0 and groups == 4):
@@ -602,10 +614,10 @@ class HipExecutor:
     """plan.add with the measured tile configuration of this shape, when one is known."""
     if kind in ("conv", "wgrad"):
       desc = autotune.apply(kind, desc)
+    if kind in ("conv", "wgrad") and desc.get("batch") is None:
+      desc = self._in_step_choice(plan, kind, desc, lane)
     if kind == "wgrad" and self.deterministic:
       desc = dict(desc, splits=1)
-    if kind == "wgrad" and lane == 1:
-      desc = self._lane_tile(desc)
     if kind == "conv" and plan is getattr(self, "bwd_plan", None) and os.environ.get("DTF_DGRAD_LANE_MAP"):
       table = dict(e.split(":") for e in os.environ["DTF_DGRAD_LANE_MAP"].split(","))   # A/B runs
       if str(desc.get("cfg", 0)) in table:

@@ -236,30 +236,35 @@ def save(path: Optional[str] = None):
   _dirty = False
 
 
-# ---- weight gradients next to the main lane ------------------------------------------------
-# The table above is measured on kernels running alone.  A weight gradient on the side lane of a
-# large step runs next to the main lane's memory-bound kernels, where another tile can be the
-# better neighbour (fewer blocks, less operand traffic through L2).  `tuned_gfx950_lane.json`
-# holds, per weight-gradient signature, the choice that minimised the *step* time
-# (`scripts/tune_lane_wgrad.py`: coordinate search over shape classes, whole training steps
-# timed); `LANE_OVERRIDE` lets that search try candidates without touching the file.
-LANE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950_lane.json")
-LANE_OVERRIDE: Dict[str, Dict[str, int]] = {}
-_lane_cache: Optional[Dict[str, Dict[str, int]]] = None
+# ---- choices measured in whole training steps -------------------------------------------------
+# The table above is measured on kernels running alone, back to back on hot caches.  Inside a step
+# a launch meets cold caches and, in the backward pass, the other lane's kernels: a weight
+# gradient on the side lane competes with the main lane for L2 and memory bandwidth, and the
+# tile that is fastest alone is not always the one that gives the shortest step.
+# `tuned_gfx950_step.json` holds, per launch signature, the choice that minimised the *step* time
+# (`scripts/tune_in_step.py`: coordinate search over shape classes, whole training steps timed);
+# `STEP_OVERRIDE` lets that search try candidates without touching the file.
+STEP_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950_step.json")
+STEP_OVERRIDE: Dict[str, Dict[str, int]] = {}
+_step_cache: Optional[Dict[str, Dict[str, int]]] = None
 
 
-def lane_lookup(desc: Dict) -> Optional[Dict[str, int]]:
-  """In-step choice {cfg, splits} for a side-lane weight gradient, or None."""
-  global _lane_cache
-  sig = signature("wgrad", desc)
-  if sig in LANE_OVERRIDE:
-    return LANE_OVERRIDE[sig]
-  if _lane_cache is None:
-    _lane_cache = {}
-    path = os.environ.get("DTF_AUTOTUNE_LANE_CACHE") or LANE_PATH
+def step_signature(kind: str, desc: Dict, lane: int = 0) -> str:
+  """Signature of a launch in the in-step table: the shape key plus the lane it runs on."""
+  return signature(kind, desc) + ("|lane=1" if lane else "")
+
+
+def step_lookup(kind: str, desc: Dict, lane: int = 0) -> Optional[Dict[str, int]]:
+  """In-step choice {cfg[, splits]} for a launch, or None."""
+  global _step_cache
+  sig = step_signature(kind, desc, lane)
+  if sig in STEP_OVERRIDE:
+    return STEP_OVERRIDE[sig]
+  if _step_cache is None:
+    _step_cache = {}
+    path = os.environ.get("DTF_AUTOTUNE_STEP_CACHE") or STEP_PATH
     if (os.environ.get("DTF_AUTOTUNE_IGNORE_CACHE", "0") != "1"
-        and os.environ.get("DTF_AUTOTUNE_IGNORE_LANE", "0") != "1" and os.path.exists(path)):
+        and os.environ.get("DTF_AUTOTUNE_IGNORE_STEP", "0") != "1" and os.path.exists(path)):
       with open(path) as f:
-        _lane_cache = json.load(f)
-  return _lane_cache.get(sig)
-
+        _step_cache = json.load(f)
+  return _step_cache.get(sig)
