@@ -570,8 +570,7 @@ class HipExecutor:
     (`ops/tuned_gfx950_step.json`, choices that minimised the time of whole training steps,
     `scripts/tune_in_step.py`) when there is one, else the stand-alone table's choice - for
     weight gradients on the side lane after the neighbour rule of `_lane_tile`."""
-    if plan is getattr(self, "eval_plan", None) or desc.get("pro_sums") is not None \
-        or desc.get("bpro_sums") is not None:
+    if plan is getattr(self, "eval_plan", None):
       return desc
     self.__dict__.setdefault("step_launches", []).append((kind, lane, dict(desc)))
     hit = autotune.step_lookup(kind, desc, lane)

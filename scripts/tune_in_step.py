@@ -37,7 +37,8 @@ from distributed_tensorflow_amd.train.optimizers import SGD  # noqa: E402
 from distributed_tensorflow_amd.utils import logging  # noqa: E402
 
 
-def step_ms(args, device, images, labels, steps=30, warm=6):
+def step_ms(args, device, images, labels, warm=6):
+  steps = args.steps
   """Builds the executor with the current `autotune.STEP_OVERRIDE` and times `steps` steps."""
   spec = getattr(models, args.model)()
   model = Model(spec, dtype=args.dtype, device=device, executor="hip")
@@ -63,7 +64,9 @@ def candidates(kind, lane, d):
   if kind == "conv":
     return [dict(cfg=c) for c in autotune._fwd_candidates(d)]  # pylint: disable=protected-access
   cur = int(d.get("splits", 1))
-  tiles = [16, 24, 17, 18, 0] if d["Cout"] >= 128 else [17, 1, 21, 5]
+  if d["Cout"] < 128:                       # narrow layers: everything the stand-alone tuner tries
+    return [dict(cfg=c, splits=s) for c, s in autotune._wgrad_candidates(d)]  # pylint: disable=protected-access
+  tiles = [16, 24, 17, 18, 0]
   out = []
   for t in tiles:
     for mul in (1.0, 0.75, 1.5):
@@ -81,6 +84,7 @@ def main():
   ap.add_argument("--kinds", default="conv,wgrad")
   ap.add_argument("--out", default=autotune.STEP_PATH)
   ap.add_argument("--margin", type=float, default=0.02, help="ms a candidate must win by")
+  ap.add_argument("--steps", type=int, default=30, help="timed steps per measurement")
   ap.add_argument("--budget_s", type=float, default=1000.0, help="stop starting classes after this")
   ap.add_argument("--skip", type=int, default=0, help="classes to skip (continue an earlier run)")
   a = ap.parse_args()
