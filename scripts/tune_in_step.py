@@ -87,6 +87,7 @@ def main():
   ap.add_argument("--steps", type=int, default=30, help="timed steps per measurement")
   ap.add_argument("--budget_s", type=float, default=1000.0, help="stop starting classes after this")
   ap.add_argument("--skip", type=int, default=0, help="classes to skip (continue an earlier run)")
+  ap.add_argument("--resume", action="store_true", help="start from the entries already in --out")
   a = ap.parse_args()
   logging.set_verbosity(logging.WARNING)
   t_start = time.time()
@@ -99,7 +100,7 @@ def main():
 
   autotune.STEP_OVERRIDE.clear()
   chosen = {}
-  if os.path.exists(a.out) and a.skip:
+  if os.path.exists(a.out) and (a.skip or a.resume):
     chosen = json.load(open(a.out))
     autotune.STEP_OVERRIDE.update(chosen)
   base, launches = step_ms(a, device, images, labels)
