@@ -98,7 +98,8 @@ ELEMENT_TYPES = {"bf16": (0, torch.bfloat16), "bfloat16": (0, torch.bfloat16),
 
 class HipExecutor:
   native = True
-  STATS_REPLICAS = 32     # rows of atomically accumulated BatchNorm sums per layer
+  # rows of atomically accumulated BatchNorm sums per layer (ResNet-50 step: 8 rows 20.30 ms, 16: 20.13, 32: 20.12, 64: 20.18)
+  STATS_REPLICAS = int(os.environ.get("DTF_BN_STATS_REPLICAS", "32"))
   # A data gradient also accumulates the backward statistics of the BatchNorm it feeds when the
   # gradient tensor is at most this many bytes.  The epilogue re-reads the BatchNorm input at
   # the size of its output: for small tensors that replaces a reduction sweep which is pure
