@@ -289,6 +289,24 @@ def preprocess_image(image_buffer: bytes, bbox: np.ndarray, output_height: int,
       flip = bool(rng.random() < 0.5)
       return fast(pixels, y, x, h, w, output_height, output_width, 0, 0, output_height,
                   output_width, flip, list(_CHANNEL_MEANS))
+    region = _jpeg_region_decoder()
+    hdr = region.jpeg_header(image_buffer) if region is not None else None
+    if hdr is not None and hdr[2] in (1, 3):
+      # evaluation: the central crop of the resized image needs the middle 7/8 of the source
+      # only; rows and MCU-aligned columns outside it are not decoded
+      height, width = int(hdr[0]), int(hdr[1])
+      new_h, new_w = _smallest_size_at_least(height, width, _RESIZE_MIN)
+      top, left = (new_h - output_height) // 2, (new_w - output_width) // 2
+      sy, sx = np.float32(height) / np.float32(new_h), np.float32(width) / np.float32(new_w)
+      y0 = min(int(np.float32(top) * sy), height - 1)
+      y1 = min(int(np.float32(top + output_height - 1) * sy) + 1, height - 1)
+      x0 = min(int(np.float32(left) * sx), width - 1)
+      x1 = min(int(np.float32(left + output_width - 1) * sx) + 1, width - 1)
+      res = region.jpeg_decode_region(image_buffer, y0, x0, y1 - y0 + 1, x1 - x0 + 1, 1)
+      if res is not None:
+        pixels, oy, ox, _ih, _iw = res
+        return fast(pixels, 0, 0, height, width, new_h, new_w, top, left, output_height,
+                    output_width, False, list(_CHANNEL_MEANS), oy, ox)
     pixels = np.asarray(_decode(image_buffer))           # uint8 [H, W, 3]
     height, width = pixels.shape[0], pixels.shape[1]
     new_h, new_w = _smallest_size_at_least(height, width, _RESIZE_MIN)

@@ -330,16 +330,30 @@ class CifarLoader {
 // * (input size / output size), the two nearest samples per axis, no antialiasing.
 //   out[i][j] = resized(src[y:y+h, x:x+w] -> [rh, rw])[i + top][j + left] - mean
 // with the flip applied to the output columns.
+// `origin_y`, `origin_x`: `src` holds only the part of the image that starts there (a region
+// decode); the box and the sampling rule keep referring to the whole image, and every sample the
+// output window needs must lie inside the part.
 py::array_t<float> crop_resize_bilinear(
     py::array_t<uint8_t, py::array::c_style | py::array::forcecast> src, int y, int x, int h, int w,
     int rh, int rw, int top, int left, int out_h, int out_w, bool flip,
-    const std::vector<float>& means) {
+    const std::vector<float>& means, int origin_y, int origin_x) {
   if (src.ndim() != 3) throw std::invalid_argument("crop_resize_bilinear: image must be [H, W, C]");
   const int H = (int)src.shape(0), W = (int)src.shape(1), C = (int)src.shape(2);
-  if (y < 0 || x < 0 || h <= 0 || w <= 0 || y + h > H || x + w > W)
+  if (y < 0 || x < 0 || h <= 0 || w <= 0 || origin_y < 0 || origin_x < 0)
     throw std::invalid_argument("crop_resize_bilinear: crop box outside the image");
-  if (rh <= 0 || rw <= 0 || top < 0 || left < 0 || top + out_h > rh || left + out_w > rw)
+  if (rh <= 0 || rw <= 0 || top < 0 || left < 0 || top + out_h > rh || left + out_w > rw ||
+      out_h <= 0 || out_w <= 0)
     throw std::invalid_argument("crop_resize_bilinear: output window outside the resized image");
+  {
+    // first / last source row and column the window samples (the rule below)
+    const float sy = (float)h / (float)rh, sx = (float)w / (float)rw;
+    const int r_first = y + std::min((int)((float)top * sy), h - 1);
+    const int r_last = y + std::min((int)((float)(top + out_h - 1) * sy) + 1, h - 1);
+    const int c_first = x + std::min((int)((float)left * sx), w - 1);
+    const int c_last = x + std::min((int)((float)(left + out_w - 1) * sx) + 1, w - 1);
+    if (r_first < origin_y || r_last >= origin_y + H || c_first < origin_x || c_last >= origin_x + W)
+      throw std::invalid_argument("crop_resize_bilinear: crop box outside the image");
+  }
   if (!means.empty() && (int)means.size() != C)
     throw std::invalid_argument("crop_resize_bilinear: one mean per channel");
   py::array_t<float> out({out_h, out_w, C});
@@ -363,15 +377,18 @@ py::array_t<float> crop_resize_bilinear(
     // per output row: blend the two source rows over the crop's width (a contiguous, vectorisable
     // sweep), then pick / blend the two neighbouring columns of every output pixel
     std::vector<float> line((size_t)w * C);
+    // columns of the crop the window touches: only those are blended (and need to exist in `src`)
+    int e_lo = x0[0], e_hi = x1[0];
+    for (int j = 0; j < out_w; ++j) { e_lo = std::min(e_lo, x0[j]); e_hi = std::max(e_hi, x1[j]); }
+    e_hi += C;
     for (int i = 0; i < out_h; ++i) {
       const float f = (float)(i + top) * sy;
       const int lo = (int)f;
       const float fy = f - (float)lo;
-      const uint8_t* r0 = in + ((size_t)(y + std::min(lo, h - 1)) * W + x) * C;
-      const uint8_t* r1 = in + ((size_t)(y + std::min(lo + 1, h - 1)) * W + x) * C;
+      const uint8_t* r0 = in + ((ptrdiff_t)(y + std::min(lo, h - 1) - origin_y) * W + (x - origin_x)) * C;
+      const uint8_t* r1 = in + ((ptrdiff_t)(y + std::min(lo + 1, h - 1) - origin_y) * W + (x - origin_x)) * C;
       float* t = line.data();
-      const int n = w * C;
-      for (int e = 0; e < n; ++e) {
+      for (int e = e_lo; e < e_hi; ++e) {
         const float a = (float)r0[e];
         t[e] = a + ((float)r1[e] - a) * fy;
       }
@@ -433,7 +450,7 @@ PYBIND11_MODULE(_dtf_data, m) {
   m.def("crop_resize_bilinear", &crop_resize_bilinear, py::arg("image"), py::arg("y"), py::arg("x"),
         py::arg("h"), py::arg("w"), py::arg("resized_h"), py::arg("resized_w"), py::arg("top"),
         py::arg("left"), py::arg("out_h"), py::arg("out_w"), py::arg("flip") = false,
-        py::arg("means") = std::vector<float>());
+        py::arg("means") = std::vector<float>(), py::arg("origin_y") = 0, py::arg("origin_x") = 0);
   py::class_<CifarLoader>(m, "CifarLoader")
       .def(py::init<const std::vector<std::string>&, bool, int, int, int, uint64_t, int, bool, int>(),
            py::arg("files"), py::arg("is_training"), py::arg("batch_size"),

@@ -411,6 +411,24 @@ def test_training_decode_inside_the_crop_box_matches_the_full_decode(monkeypatch
     monkeypatch.delenv("DTF_JPEG_REGION")
     assert a.shape == b.shape == (224, 224, 3)
     assert np.abs(a - b).max() <= 24.0 and np.abs(a - b).mean() < 0.05
+  # evaluation: the central crop of the resized image is decoded as a region as well
+  for size in ((500, 375), (375, 500), (300, 1000), (224, 224)):
+    b2 = io.BytesIO()
+    Image.fromarray(small).resize(size, Image.BICUBIC).save(b2, format="JPEG", quality=90)
+    a = ip.preprocess_image(b2.getvalue(), bbox, 224, 224, 3, False)
+    monkeypatch.setenv("DTF_JPEG_REGION", "0")
+    b = ip.preprocess_image(b2.getvalue(), bbox, 224, 224, 3, False)
+    monkeypatch.delenv("DTF_JPEG_REGION")
+    assert a.shape == b.shape == (224, 224, 3)
+    assert np.abs(a - b).max() <= 24.0 and np.abs(a - b).mean() < 0.05, size
+  # the resize of a part of the image (origin_y / origin_x) equals the resize of the whole
+  whole = ext.crop_resize_bilinear(full, 0, 0, 375, 500, 256, 341, 16, 58, 224, 224, False, [1., 2., 3.])
+  part = ext.crop_resize_bilinear(full[20:360, 80:430].copy(), 0, 0, 375, 500, 256, 341, 16, 58, 224, 224,
+                                  False, [1., 2., 3.], 20, 80)
+  assert np.array_equal(whole, part)
+  with pytest.raises(ValueError):       # the window needs rows the part does not hold
+    ext.crop_resize_bilinear(full[40:360, 80:430].copy(), 0, 0, 375, 500, 256, 341, 16, 58, 224, 224,
+                             False, [1., 2., 3.], 40, 80)
   # not a JPEG: the header probe declines, PIL decodes
   png = io.BytesIO()
   picture.save(png, format="PNG")
