@@ -146,6 +146,14 @@ class _Rebatcher:
     self.loader = loader
     self.batch_size = int(batch_size)
     self.drop_remainder = drop_remainder
+    self.num_samples: Optional[int] = None     # set by whoever knows the stream's sample count
+
+  def __len__(self):
+    if self.num_samples is None:
+      raise TypeError("this input stream has no known length (its sample count was not given): "
+                      "pass `steps` / `steps_per_epoch` explicitly")
+    n, bs = self.num_samples, self.batch_size
+    return n // bs if self.drop_remainder else -(-n // bs)
 
   def __iter__(self):
     bs = self.batch_size
@@ -269,7 +277,5 @@ def process_record_dataset(dataset: RecordDataset, is_training: bool, batch_size
   pf = DevicePrefetcher(loader, device or torch.device("cpu"),
                         depth=3 if tf_data_experimental_slack else 2, delay_ms=delay)
   pf.batch_size = batch_size
-  if num_samples is not None:
-    n = num_samples // batch_size if drop_remainder else -(-num_samples // batch_size)
-    pf.__len__ = lambda: n  # type: ignore[assignment]
+  loader.num_samples = num_samples     # DevicePrefetcher.__len__ asks the loader
   return pf

@@ -1290,14 +1290,26 @@ class HipExecutor:
     if self._seen_version != self.store.version:
       self.params_updated()
 
-  def _stage(self, images: torch.Tensor, labels: Optional[torch.Tensor]):
+  def _same_device(self, t: torch.Tensor) -> bool:
+    """`t` lives on the executor's GPU (an index-less `cuda` device means the current one)."""
+    if not t.is_cuda or self.device.type != "cuda":
+      return False
+    mine = self.device.index if self.device.index is not None else torch.cuda.current_device()
+    return t.device.index == mine
+
+  def _stage(self, images: torch.Tensor, labels: Optional[torch.Tensor],
+             allow_direct: bool = False):
+    """Makes the batch visible to the plans.  `allow_direct` (training steps only: the eager
+    training path is the one that launches the preprocessing kernel on a foreign pointer)
+    lets that launch read the caller's device tensor in place; evaluation and prediction run
+    `eval_plan`, whose preprocessing launch reads the planned input buffer, so they copy."""
     if tuple(images.shape) != tuple(self.images.shape):
       raise ValueError("HipExecutor planned for input %s, got %s"
                        % (tuple(self.images.shape), tuple(images.shape)))
     self._direct_in = None
     if images.data_ptr() != self.images.data_ptr():
-      if (self.use_graph is False and self._pre_index is not None and images.is_cuda
-          and images.device == self.device and images.dtype == self.images.dtype
+      if (allow_direct and self.use_graph is False and self._pre_index is not None
+          and self._same_device(images) and images.dtype == self.images.dtype
           and images.is_contiguous() and os.environ.get("DTF_DIRECT_INPUT", "1") != "0"):
         # eager launch: the preprocessing launch of this step reads the caller's batch in place
         # (a prefetcher hands over a fresh device tensor every step; copying it into the
@@ -1324,7 +1336,7 @@ class HipExecutor:
     self._soft_joins = bool(soft_joins and on_bucket_ready is not None)
     with torch.cuda.device(self.device):
       self._ensure_packed()
-      self._stage(images, labels)
+      self._stage(images, labels, allow_direct=True)
       self._set_loss_scale(loss_scale)
       if self.use_graph is None:
         self._calibrate_step(on_bucket_ready)

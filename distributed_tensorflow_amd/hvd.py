@@ -50,7 +50,27 @@ def init(use_gpu: Optional[bool] = None) -> Communicator:
     if use_gpu is None:
       use_gpu = torch.cuda.is_available()
     _state["comm"] = get_communicator(task, use_gpu=use_gpu)
+    _publish_host(_state["comm"])
   return _state["comm"]
+
+
+def _publish_host(c: Communicator):
+  """Every rank calls `init()`: this is where the ranks exchange their host names (through the
+  job's key-value store), so that `local_size()` is a purely local query afterwards, as in
+  Horovod, and never a hidden collective."""
+  import os  # pylint: disable=import-outside-toplevel
+  if "LOCAL_WORLD_SIZE" in os.environ:
+    _state["local_size"] = int(os.environ["LOCAL_WORLD_SIZE"])
+    return
+  if c.world_size <= 1:
+    _state["local_size"] = 1
+    return
+  import socket  # pylint: disable=import-outside-toplevel
+  me = socket.gethostname()
+  store = c.store()
+  store.set("hvd/host/%d" % c.rank, me)
+  hosts = [store.get("hvd/host/%d" % r).decode() for r in range(c.world_size)]   # blocks
+  _state["local_size"] = sum(1 for h in hosts if h == me)
 
 
 def shutdown():
@@ -82,25 +102,12 @@ def size() -> int:
 
 
 def local_size() -> int:
-  """Ranks of this job on this host (`hvd.local_size()`).
+  """Ranks of this job on this host (`hvd.local_size()`): a local query.
 
   Launchers that spawn the ranks of a host export LOCAL_WORLD_SIZE; without it (ranks started
-  by hand from a TF_CONFIG, one per terminal or host) the ranks exchange their host names once
-  through the job's key-value store and count the matches."""
-  import os  # pylint: disable=import-outside-toplevel
-  if "LOCAL_WORLD_SIZE" in os.environ:
-    return int(os.environ["LOCAL_WORLD_SIZE"])
-  if "local_size" not in _state:
-    c = _c()
-    if c.world_size <= 1:
-      _state["local_size"] = 1
-    else:
-      import socket  # pylint: disable=import-outside-toplevel
-      me = socket.gethostname()
-      store = c.store()
-      store.set("hvd/host/%d" % c.rank, me)
-      hosts = [store.get("hvd/host/%d" % r).decode() for r in range(c.world_size)]   # blocks
-      _state["local_size"] = sum(1 for h in hosts if h == me)
+  by hand from a TF_CONFIG, one per terminal or host) the ranks exchanged their host names once
+  inside `init()` and the count of matches was cached there."""
+  _c()
   return _state["local_size"]
 
 

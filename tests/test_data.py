@@ -439,3 +439,18 @@ def test_training_decode_inside_the_crop_box_matches_the_full_decode(monkeypatch
   assert np.array_equal(c, d)
   # a truncated file does not crash the worker: the decoder reports failure or pads like PIL
   assert ext.jpeg_decode_region(raw[:200], 0, 0, 10, 10, 1) is None
+
+
+def test_rebatched_stream_reports_its_length_or_says_why_not():
+  """`Model.evaluate(x, steps=None)` asks `len(x)`: a stream whose sample count is known answers,
+  one without it raises an error that names the remedy (not a bare TypeError from `len`)."""
+  from distributed_tensorflow_amd.data.pipeline import DevicePrefetcher, _Rebatcher
+  batches = [(torch.zeros(4, 2), torch.zeros(4)), (torch.zeros(3, 2), torch.zeros(3))]
+  rb = _Rebatcher(batches, 4, drop_remainder=False)
+  pf = DevicePrefetcher(rb, torch.device("cpu"))
+  with pytest.raises(TypeError, match="no known length"):
+    len(pf)
+  rb.num_samples = 7
+  assert len(pf) == 2 and len(list(pf)) == 2
+  rb.drop_remainder = True
+  assert len(pf) == 1

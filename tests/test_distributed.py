@@ -264,7 +264,10 @@ hvd.init(use_gpu=False)
 assert hvd.size() == world and hvd.rank() == rank and hvd.local_rank() == rank
 assert hvd.local_size() == world                       # from the launcher's LOCAL_WORLD_SIZE
 del os.environ["LOCAL_WORLD_SIZE"]; hvd._state.pop("local_size", None)
-assert hvd.local_size() == world                       # counted from the ranks' host names
+hvd._publish_host(hvd._c())                            # what init() does without the variable:
+assert hvd._state["local_size"] == world               # counted from the ranks' host names
+if rank == 0:
+  assert hvd.local_size() == world                     # a local query: one rank alone may ask
 t = torch.full((4,), float(rank + 1))
 avg = hvd.allreduce(t); tot = hvd.allreduce(t, average=False)
 b = hvd.broadcast(torch.full((2,), float(rank + 7)), root_rank=1)

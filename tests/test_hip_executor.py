@@ -556,3 +556,36 @@ def test_batchnorm_prologue_plan_matches_separate_sweeps(monkeypatch):
   # moving statistics were updated by the fused launches as well
   assert torch.allclose(sa.state, sb.state, rtol=1e-2, atol=1e-3)
   assert torch.allclose(sa.state, sc.state, rtol=1e-2, atol=1e-3)
+
+
+def test_eager_executor_evaluates_the_batch_it_is_given():
+  """An eager executor lets its training step read the caller's batch in place; evaluation and
+  prediction must still see *their* batch, not the one staged last (store on an indexed device,
+  as the drivers build it)."""
+  from distributed_tensorflow_amd.engine.hip_executor import HipExecutor
+  spec = models.resnet20()
+  dev = torch.device("cuda", 0)
+  st_h, st_t = ParamStore(spec, dev, 3), ParamStore(spec, dev, 3)
+  hx = HipExecutor(spec, st_h, 16, "bf16", use_graph=False)
+  tx = TorchExecutor(spec, st_t, 16, "fp32")
+  g = torch.Generator().manual_seed(7)
+  xa = (torch.randn(16, 32, 32, 3, generator=g) * 60 + 120).to(dev)
+  xb = (torch.randn(16, 32, 32, 3, generator=g) * 20 + 30).to(dev)
+  ya = torch.randint(0, 10, (16,), generator=g).to(dev)
+  yb = torch.randint(0, 10, (16,), generator=g).to(dev)
+  hx.train_step(xa, ya, 1.0)
+  assert hx._direct_in is None                      # consumed by the step
+  tx.train_step(xa, ya, 1.0)
+  st_t.params.copy_(st_h.params)                    # same weights, same moving statistics
+  st_t.state.copy_(st_h.state)
+  st_t.version += 1
+  st_h.version += 1
+  lb_h, _ = hx.eval_step(xb, yb)
+  lb_t, _ = tx.eval_step(xb, yb)
+  la_t, _ = tx.eval_step(xa, ya)
+  torch.cuda.synchronize()
+  assert abs(la_t.item() - lb_t.item()) > 0.05      # the two batches are told apart by the loss
+  assert lb_h.item() == pytest.approx(lb_t.item(), rel=3e-2, abs=3e-2)
+  pb = hx.predict(xb)
+  pa = hx.predict(xa)
+  assert not torch.allclose(pa, pb, atol=1e-3)
