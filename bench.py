@@ -52,7 +52,11 @@ def main() -> int:
   ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"],
                   help="compute precision (default: bf16 on the GPU, fp32 on the CPU)")
   ap.add_argument("--num_packs", type=int, default=4, help="gradient fusion buckets")
-  ap.add_argument("--all_reduce_alg", default=None)
+  ap.add_argument("--all_reduce_alg", default=None,
+                  help="nccl (default) | ring | hierarchical_copy | mesh")
+  ap.add_argument("--comm", default="auto", choices=["auto", "native", "torch"],
+                  help="data plane of the gradient collectives: the engine's RCCL communicator "
+                       "(auto on GPUs) or torch.distributed")
   ap.add_argument("--no_graph", action="store_true")
   ap.add_argument("--rehearse_collectives", action="store_true",
                   help="1 GPU only: run the multi-GPU code path (segmented backward, one RCCL "
@@ -99,7 +103,7 @@ def main() -> int:
     os.environ["DTF_REHEARSE_COLLECTIVES"] = "1"
   if a.gpus > 1 or a.rehearse_collectives:
     strat = strategy_lib.MirroredStrategy(use_gpu=on_gpu, all_reduce_alg=a.all_reduce_alg,
-                                          num_packs=a.num_packs)
+                                          num_packs=a.num_packs, comm_kind=a.comm)
     device = strat.device
     rank = strat.rank
   else:
@@ -146,6 +150,10 @@ def main() -> int:
   for _ in range(8):
     opt.learning_rate = lr_at(0)
     model.train_on_batch(images, labels)
+  # effective environment, process group, reducer and launch mode: a failing first multi-GPU run
+  # must be diagnosable from its log alone
+  from distributed_tensorflow_amd.utils.runtime_report import log_runtime_report
+  log_runtime_report(strat, model, rank)
   for i in range(a.warmup):
     opt.learning_rate = lr_at(i)          # the reference's per-batch schedule (warm-up phase)
     last = model.train_on_batch(images, labels)

@@ -113,6 +113,10 @@ def define_keras_flags(dynamic_loss_scale=True):
                   "command line).")
   f.DEFINE_string("task_type", None, "ps | worker | chief: job of this process in the cluster.")
   f.DEFINE_string("executor", "auto", "auto | hip | torch: execution back end.")
+  f.DEFINE_string("comm", "auto", "auto | native | torch: data plane of the gradient collectives "
+                  "and parameter-server transfers on GPUs - the engine's own RCCL communicator "
+                  "(issued from C++, capturable into the step's hipGraph, fail-fast watchdog) or "
+                  "torch.distributed.  auto: native whenever the job runs on RCCL.")
   f.DEFINE_integer("seed", 0, "Seed of the variable initialisers.")
   f.DEFINE_string("resume", None, "Keras-layout HDF5 checkpoint to restore before training.")
   f.DEFINE_integer("fusion_threshold_mb", None,

@@ -103,9 +103,14 @@ class HipExecutor:
   # A data gradient also accumulates the backward statistics of the BatchNorm it feeds when the
   # gradient tensor is at most this many bytes.  The epilogue re-reads the BatchNorm input at
   # the size of its output: for small tensors that replaces a reduction sweep which is pure
-  # launch latency (ResNet-56 step 3.19 -> 2.97 ms), for large ones it costs more than the
-  # sweep it saves (ResNet-50 with every layer fused: 23.37 vs 23.10 ms).
-  BWD_STATS_SMALL_BYTES = 8 << 20
+  # launch latency (ResNet-56 step 3.19 -> 2.97 ms).  For large tensors the two are equal: the
+  # sweep reads dz and y, the epilogue y only, but dz was written by the launch before and the
+  # sweep - walking it from the end that launch touched last - finds it in the 256 MB
+  # memory-side cache, so both forms fetch the same bytes from memory (ResNet-50 bs256, serial
+  # kernel time with every layer fused: reduction sweeps -1.48 ms, convolutions +1.53 ms; step
+  # 20.15 ms at 8 MB, 20.07 - 20.10 at 16 - 128 MB, 20.19 at 256 MB, 20.35 with every layer;
+  # `results/bstats_threshold_sweep.txt`).
+  BWD_STATS_SMALL_BYTES = 64 << 20
   # A training BatchNorm (+ ReLU) whose only consumer is a unit-stride convolution is folded
   # into that convolution (it normalises its operand on the way into LDS and writes the
   # normalised tensor on the side) when the tensor is at most this many bytes: for the

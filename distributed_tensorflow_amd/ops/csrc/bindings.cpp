@@ -382,7 +382,7 @@ Launch make_op(const std::string& kind, const py::dict& d) {
   }
   if (kind == "allreduce") {
     // a collective as a plan entry: `comm` is the address of a live RcclComm (kept alive by its
-    // Python owner); mode 0 one-shot, 1 reduce-scatter + all-gather, 2 by message size
+    // Python owner); mode 0 one-shot, 1 reduce-scatter + all-gather, 2 by message size, 3 all-link mesh exchange
     auto* comm = reinterpret_cast<dtf::RcclComm*>(get<uintptr_t>(d, "comm"));
     auto buf = ptr<void>(d, "buf");
     const size_t count = get<size_t>(d, "count");
@@ -391,6 +391,7 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     return [=](hipStream_t s) {
       if (mode == 0) comm->all_reduce(buf, count, dt, s);
       else if (mode == 1) comm->all_reduce_direct(buf, count, dt, s);
+      else if (mode == 3) comm->all_reduce_mesh(buf, count, dt, s);
       else comm->all_reduce_auto(buf, count, dt, s);
     };
   }
@@ -678,6 +679,16 @@ PYBIND11_MODULE(_dtf_native, m) {
       .def_property_readonly("handle", [](dtf::RcclComm& c) { return reinterpret_cast<uintptr_t>(&c); })
       .def_readwrite("direct_min_bytes", &dtf::RcclComm::direct_min_bytes)
       .def_readonly("collectives", &dtf::RcclComm::collectives)
+      .def("async_error", &dtf::RcclComm::async_error, py::call_guard<py::gil_scoped_release>(),
+           "'' while the communicator is healthy; else the error text (the communicator is aborted)")
+      .def("abort", &dtf::RcclComm::abort, py::call_guard<py::gil_scoped_release>())
+      .def("start_watchdog", &dtf::RcclComm::start_watchdog, py::arg("interval_ms") = 1000,
+           py::arg("exit_code") = 0)
+      .def("stop_watchdog", &dtf::RcclComm::stop_watchdog, py::call_guard<py::gil_scoped_release>())
+      .def_property_readonly("failed", &dtf::RcclComm::failed)
+      .def("all_reduce_mesh", [](dtf::RcclComm& c, uintptr_t p, size_t n, int dt, uintptr_t s) {
+             c.all_reduce_mesh(reinterpret_cast<void*>(p), n, dt, reinterpret_cast<hipStream_t>(s)); },
+           py::arg("ptr"), py::arg("count"), py::arg("dt") = 2, py::arg("stream") = 0)
       .def("all_reduce", [](dtf::RcclComm& c, uintptr_t p, size_t n, int dt, uintptr_t s) {
              c.all_reduce(reinterpret_cast<void*>(p), n, dt, reinterpret_cast<hipStream_t>(s)); },
            py::arg("ptr"), py::arg("count"), py::arg("dt") = 2, py::arg("stream") = 0)

@@ -14,14 +14,33 @@ namespace conv_epi {
 
 constexpr int EPI_PLAIN = 0, EPI_BSTATS = 1, EPI_INFER = 2;
 
+// Value of lane ^ (1 << T) inside a row of 16 lanes, without a trip through the LDS crossbar
+// where the data-parallel-primitive modifiers can express the exchange: quad permutes for the
+// neighbours at distance 1 and 2, a rotation by 8 for distance 8; distance 4 is a swizzle.
+// Every lane of the wave must be active.
+template <int T>
+__device__ __forceinline__ float lane_xor16(float v) {
+  const int i = __builtin_bit_cast(int, v);
+  int r;
+  if constexpr (T == 0) r = __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xF, 0xF, true);         // quad_perm [1,0,3,2]
+  else if constexpr (T == 1) r = __builtin_amdgcn_update_dpp(i, i, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  else if constexpr (T == 2) r = __builtin_amdgcn_ds_swizzle(i, 0x101F);                     // lane ^ 4
+  else r = __builtin_amdgcn_update_dpp(i, i, 0x128, 0xF, 0xF, true);                         // row_ror:8
+  return __builtin_bit_cast(float, r);
+}
+
 // Sum over the 16 lanes that share lane/16 (the 16 pixels of an MFMA column block), leaving
 // the totals scattered over those lanes: a halving butterfly - at step T a lane keeps one
 // half of its values and hands the other half to lane ^ (1 << T) - so NV values cost NV - 1
-// shuffles in total instead of 4 * NV.  Afterwards v[0 .. (NV >> steps) - 1] of a lane hold the
+// exchanges in total instead of 4 * NV.  Afterwards v[0 .. (NV >> steps) - 1] of a lane hold the
 // totals of the original indices  base + j,  base = sum_T bit_T(lane) * (NV >> (T + 1)).
-template <int NV, int N, int T>
+// Steps T .. TEND - 1 are run; N is the number of values still held when step T starts.
+// DPP selects how values cross lanes: the modifiers / swizzle of lane_xor16, or the LDS crossbar
+// (`__shfl_xor`).  The forward epilogue keeps the crossbar: with the modifiers the compiler's
+// schedule of its 31 exchanges next to 64 live accumulators overflows the 128-register budget.
+template <int NV, int N, int T, int TEND = 4, bool DPP = false>
 __device__ __forceinline__ void butterfly16(float (&v)[NV], int fr) {
-  if constexpr (T < 4) {
+  if constexpr (T < TEND) {
     if constexpr (N > 1) {
       constexpr int H = N / 2;
       const bool up = (fr >> T) & 1;
@@ -29,12 +48,12 @@ __device__ __forceinline__ void butterfly16(float (&v)[NV], int fr) {
       for (int i = 0; i < H; ++i) {
         const float send = up ? v[i] : v[i + H];
         const float keep = up ? v[i + H] : v[i];
-        v[i] = keep + __shfl_xor(send, 1 << T);
+        v[i] = keep + (DPP ? lane_xor16<T>(send) : __shfl_xor(send, 1 << T));
       }
-      butterfly16<NV, H, T + 1>(v, fr);
+      butterfly16<NV, H, T + 1, TEND, DPP>(v, fr);
     } else {
-      v[0] += __shfl_xor(v[0], 1 << T);
-      butterfly16<NV, 1, T + 1>(v, fr);
+      v[0] += DPP ? lane_xor16<T>(v[0]) : __shfl_xor(v[0], 1 << T);
+      butterfly16<NV, 1, T + 1, TEND, DPP>(v, fr);
     }
   }
 }
@@ -42,17 +61,20 @@ __device__ __forceinline__ void butterfly16(float (&v)[NV], int fr) {
 
 // Epilogue of a data gradient that also accumulates the backward reductions of the BatchNorm
 // whose output gradient it writes (sum g, sum g*y per channel; g = the stored value gated by the
-// layer's ReLU mask, y = the layer's input).  Three phases:
-//   1. every load of the epilogue (y and its mask, addend and its mask, for all MR pixels) is
-//      issued before anything is stored: written in the store loop they cannot be hoisted over
-//      the stores (the tensors may alias for all the compiler knows), which put 2 * MR memory
-//      latencies back to back in every wave and made this fusion lose against the separate
-//      reduction sweep on large tensors;
-//   2. results are stored pixel by pixel, a lane's channels in consecutive 16-byte stores (splitting
-//      a pixel's bytes over two passes costs ~28 % on the bandwidth-bound layers: partial lines);
-//      the rounded, gated values replace the accumulators;
-//   3. statistics per group of 8 channels from the registers, reduced over the 16 pixel lanes and
-//      added to the replica row.
+// layer's ReLU mask, y = the layer's input).  Bias-free (host check).
+//
+// A software pipeline over the wave's MR pixel blocks, one block deep: the loads of block mr + 1
+// (y and its mask bits, addend and its mask bits) are issued before block mr is stored - written
+// behind the stores they could not be hoisted over them (the tensors may alias for all the
+// compiler knows) and every wave would pay a memory latency per block - and nothing of a block
+// stays live once it is done:
+//   * a pixel's channels of a lane are stored back to back in 16-byte pieces (splitting a pixel's
+//     bytes over two passes costs ~28 % on the bandwidth-bound layers: partial lines);
+//   * the rounded, gated values of a piece and their products with y go through the 16-lane
+//     butterfly at once (data-parallel-primitive adds, no LDS crossbar), so a lane carries one
+//     running sum per piece from block to block instead of 2 * CPL.
+// Registers: the accumulators, two sets of prefetched operands and those sums fit the
+// 128-register budget of the tiles that run four waves per SIMD.
 template <int MR, int NR, bool POINTWISE, int DT>
 __device__ __forceinline__ void conv_epilogue_bstats(const ConvParams& p, f32x4 (&acc)[NR][MR],
                                                      const int m_base, const int co0, const int mt,
@@ -60,91 +82,93 @@ __device__ __forceinline__ void conv_epilogue_bstats(const ConvParams& p, f32x4 
   typedef typename Elem<DT>::T E;
   const int fr = lane & 15;
   constexpr int CPL = 4 * NR;
-  constexpr int W = CPL >= 8 ? 8 : 4;              // channels per group (one store)
+  constexpr int W = CPL >= 8 ? 8 : 4;              // channels per piece (one store)
   constexpr int HV = CPL / W;
-  constexpr int TPG = W / 4;                       // MFMA tiles per group
-  const bool vec_ok = p.ldc % W == 0;
-  size_t opixv[MR];
-  u32x4 ypre[MR][HV], apre[MR][HV];
-  uint32_t sbits[MR][HV], abits[MR][HV];
-#pragma unroll
-  for (int mr = 0; mr < MR; ++mr) {
+  constexpr int TPG = W / 4;                       // MFMA tiles per piece
+  constexpr int NV = 2 * W;                        // sums of a piece: [0, W) sum g, [W, 2 W) sum g*y
+  constexpr int HALVINGS = NV >= 16 ? 4 : 3;       // 16 values: one total left per lane; 8: per two lanes
+  struct Operands {
+    uint32_t opix;                                 // output pixel of this lane; ~0: past the last row
+    u32x4 y[HV], a[HV];
+    uint32_t bits;                                 // per piece h: ReLU bits in byte h, addend bits in byte 2 + h
+  };
+  auto fetch = [&](const int mr, Operands& q) {
     const int m = m_base + mr * 16 + fr;
-    size_t opix = 0;
+    uint32_t opix = ~0u;
     if (m < p.M) {
       if (POINTWISE) {
-        opix = (size_t)m;
+        opix = (uint32_t)m;
       } else {
         const uint32_t t = fd_div((uint32_t)m, p.divOW);
         const int ow = m - (int)t * p.OW;
         const uint32_t n = fd_div(t, p.divOH);
         const int oh = (int)t - (int)n * p.OH;
-        opix = (size_t)((int)n * p.OHfull + oh * p.OSH + p.OOH) * p.OWfull + (ow * p.OSW + p.OOW);
+        opix = (uint32_t)(((int)n * p.OHfull + oh * p.OSH + p.OOH) * p.OWfull + (ow * p.OSW + p.OOW));
       }
     }
-    opixv[mr] = opix;
+    q.opix = opix;
+    const size_t e = (size_t)opix * p.ldc + co0;
+    const size_t mb = (size_t)opix * (p.ldc >> 3) + (co0 >> 3);
+    uint32_t bits = 0;
 #pragma unroll
     for (int h = 0; h < HV; ++h) {
-      const int cg = co0 + h * W;
-      ypre[mr][h] = u32x4{0u, 0u, 0u, 0u};
-      apre[mr][h] = u32x4{0u, 0u, 0u, 0u};
-      sbits[mr][h] = 0xffu;
-      abits[mr][h] = 0xffu;
-      if (m >= p.M || !vec_ok || cg + W > p.Cout) continue;
-      const size_t e = opix * p.ldc + cg;
-      const size_t mb = opix * (p.ldc >> 3) + (cg >> 3);
+      q.y[h] = u32x4{0u, 0u, 0u, 0u};
+      q.a[h] = u32x4{0u, 0u, 0u, 0u};
+      if (opix == ~0u || co0 + h * W >= p.Cout) continue;
+      const E* yp = reinterpret_cast<const E*>(p.stats_y) + e + h * W;
       if constexpr (W == 8) {
-        ypre[mr][h] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const E*>(p.stats_y) + e);
+        q.y[h] = *reinterpret_cast<const u32x4*>(yp);
       } else {
-        const u32x2 q = *reinterpret_cast<const u32x2*>(reinterpret_cast<const E*>(p.stats_y) + e);
-        ypre[mr][h].x = q.x; ypre[mr][h].y = q.y;
+        const u32x2 t = *reinterpret_cast<const u32x2*>(yp);
+        q.y[h].x = t.x; q.y[h].y = t.y;
       }
       // W == 4: the lane's four channels are one nibble of the mask byte
-      if (p.stats_mask) sbits[mr][h] = (uint32_t)p.stats_mask[mb] >> (W == 4 ? (cg & 4) : 0);
+      uint32_t sb = 0xffu, ab = 0xffu;
+      if (p.stats_mask) sb = ((uint32_t)p.stats_mask[mb + h] >> (W == 4 ? (co0 & 4) : 0)) & 0xffu;
       if (p.addend) {
+        const E* ap = reinterpret_cast<const E*>(p.addend) + e + h * W;
         if constexpr (W == 8) {
-          apre[mr][h] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const E*>(p.addend) + e);
+          q.a[h] = *reinterpret_cast<const u32x4*>(ap);
         } else {
-          const u32x2 q = *reinterpret_cast<const u32x2*>(reinterpret_cast<const E*>(p.addend) + e);
-          apre[mr][h].x = q.x; apre[mr][h].y = q.y;
+          const u32x2 t = *reinterpret_cast<const u32x2*>(ap);
+          q.a[h].x = t.x; q.a[h].y = t.y;
         }
-        if (p.addend_mask) abits[mr][h] = (uint32_t)p.addend_mask[mb] >> (W == 4 ? (cg & 4) : 0);
+        if (p.addend_mask) ab = ((uint32_t)p.addend_mask[mb + h] >> (W == 4 ? (co0 & 4) : 0)) & 0xffu;
       }
+      bits |= (sb << (8 * h)) | (ab << (16 + 8 * h));
     }
-  }
-  float bias[CPL];
+    q.bits = bits;
+  };
+  float st[HV];                                    // this lane's share of the piece's 2 W sums
 #pragma unroll
-  for (int c = 0; c < CPL; ++c)
-    bias[c] = (p.bias != nullptr && co0 + c < p.Cout) ? p.bias[co0 + c] : 0.f;
+  for (int h = 0; h < HV; ++h) st[h] = 0.f;
+  Operands q[2];
+  fetch(0, q[0]);
 #pragma unroll
   for (int mr = 0; mr < MR; ++mr) {
-    if (m_base + mr * 16 + fr >= p.M) continue;
-    const size_t obase = opixv[mr] * p.ldc;
+    if (mr + 1 < MR) fetch(mr + 1, q[(mr + 1) & 1]);
+    const Operands& c = q[mr & 1];
 #pragma unroll
     for (int h = 0; h < HV; ++h) {
-      const int cg = co0 + h * W;
-      if (cg >= p.Cout) continue;
-      float v[W];
+      float x[W];
 #pragma unroll
       for (int t = 0; t < TPG; ++t)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[t * 4 + e] = acc[h * TPG + t][mr][e] + bias[h * W + t * 4 + e];
-      E* optr = reinterpret_cast<E*>(p.out) + obase + cg;
-      if (vec_ok && cg + W <= p.Cout) {
-        if (p.addend) {
-          const uint32_t aw[4] = {apre[mr][h].x, apre[mr][h].y, apre[mr][h].z, apre[mr][h].w};
-          const uint32_t bm = abits[mr][h];       // keep only the elements whose mask bit is set
+        for (int e = 0; e < 4; ++e) x[t * 4 + e] = acc[h * TPG + t][mr][e];
+      const uint32_t aw[4] = {c.a[h].x, c.a[h].y, c.a[h].z, c.a[h].w};
+      const uint32_t yw[4] = {c.y[h].x, c.y[h].y, c.y[h].z, c.y[h].w};
+      const uint32_t bm = c.bits >> (16 + 8 * h); // addend: only the elements whose bit is set
+      const uint32_t sb = c.bits >> (8 * h);      // g: the rounded value where the ReLU was open
+      uint32_t w[W / 2];
 #pragma unroll
-          for (int j = 0; j < W / 2; ++j) {
-            const uint32_t a = aw[j] & (((bm >> (2 * j)) & 1u ? 0xffffu : 0u) |
-                                        ((bm >> (2 * j + 1)) & 1u ? 0xffff0000u : 0u));
-            v[2 * j] += lo16<DT>(a);
-            v[2 * j + 1] += hi16<DT>(a);
-          }
-        }
-        uint32_t w[W / 2];
-#pragma unroll
-        for (int j = 0; j < W / 2; ++j) w[j] = pack2<DT>(v[2 * j], v[2 * j + 1]);
+      for (int j = 0; j < W / 2; ++j) {
+        const uint32_t a = aw[j] & (((bm >> (2 * j)) & 1u ? 0xffffu : 0u) |
+                                    ((bm >> (2 * j + 1)) & 1u ? 0xffff0000u : 0u));
+        w[j] = pack2<DT>(x[2 * j] + lo16<DT>(a), x[2 * j + 1] + hi16<DT>(a));
+      }
+      const bool live = c.opix != ~0u && co0 + h * W < p.Cout;
+      if (live) {
+        E* optr = reinterpret_cast<E*>(p.out) + ((size_t)c.opix * p.ldc + co0 + h * W);
         if constexpr (W == 8) {
           *reinterpret_cast<u32x4*>(optr) = u32x4{w[0], w[1], w[2], w[3]};
         } else {
@@ -152,58 +176,31 @@ __device__ __forceinline__ void conv_epilogue_bstats(const ConvParams& p, f32x4 
           o.x = w[0]; o.y = w[1];
           *reinterpret_cast<u32x2*>(optr) = o;
         }
-        const uint32_t sb = sbits[mr][h];         // g: the rounded value where the ReLU was open
-#pragma unroll
-        for (int j = 0; j < W / 2; ++j) {
-          acc[h * TPG + (2 * j) / 4][mr][(2 * j) % 4] = (sb >> (2 * j)) & 1u ? lo16<DT>(w[j]) : 0.f;
-          acc[h * TPG + (2 * j + 1) / 4][mr][(2 * j + 1) % 4] = (sb >> (2 * j + 1)) & 1u ? hi16<DT>(w[j]) : 0.f;
-        }
-      } else {                                     // never with statistics (host check); plain store
-        const E* aptr = p.addend ? reinterpret_cast<const E*>(p.addend) + obase + cg : nullptr;
-#pragma unroll
-        for (int c = 0; c < W; ++c) {
-          if (cg + c < p.Cout) {
-            float x = v[c];
-            if (aptr) x += to_f<DT>(aptr[c]);
-            optr[c] = from_f<DT>(x);
-          }
-          acc[h * TPG + c / 4][mr][c % 4] = 0.f;
-        }
       }
+      float v[NV];                                 // [0, W): g, [W, 2 W): g * y of this piece
+#pragma unroll
+      for (int j = 0; j < W / 2; ++j) {
+        const float lo = (live && ((sb >> (2 * j)) & 1u)) ? lo16<DT>(w[j]) : 0.f;
+        const float hi = (live && ((sb >> (2 * j + 1)) & 1u)) ? hi16<DT>(w[j]) : 0.f;
+        v[2 * j] = lo;
+        v[2 * j + 1] = hi;
+        v[W + 2 * j] = lo * lo16<DT>(yw[j]);
+        v[W + 2 * j + 1] = hi * hi16<DT>(yw[j]);
+      }
+      butterfly16<NV, NV, 0, 4, true>(v, fr);      // every lane takes part (no early exit above)
+      st[h] += v[0];
     }
   }
   if (p.stats == nullptr) return;
+  int base = 0;
 #pragma unroll
-  for (int h = 0; h < HV; ++h) {
-    const int cg = co0 + h * W;
-    float st[2 * W];
+  for (int t = 0; t < HALVINGS; ++t) base += ((fr >> t) & 1) * (NV >> (t + 1));
+  if (HALVINGS == 4 || (fr >> 3) == 0) {
+    float* dst = p.stats + (size_t)(mt % p.stats_replicas) * 2 * p.Cout;
+    const int qn = base / W, cn = base % W;        // quantity (sum g / sum g*y), channel in the piece
 #pragma unroll
-    for (int c = 0; c < 2 * W; ++c) st[c] = 0.f;
-#pragma unroll
-    for (int mr = 0; mr < MR; ++mr) {
-      if (m_base + mr * 16 + fr >= p.M) continue;
-      const uint32_t yw[4] = {ypre[mr][h].x, ypre[mr][h].y, ypre[mr][h].z, ypre[mr][h].w};
-#pragma unroll
-      for (int j = 0; j < W / 2; ++j) {
-        const float lo = acc[h * TPG + (2 * j) / 4][mr][(2 * j) % 4];
-        const float hi = acc[h * TPG + (2 * j + 1) / 4][mr][(2 * j + 1) % 4];
-        st[2 * j] += lo;
-        st[2 * j + 1] += hi;
-        st[W + 2 * j] += lo * lo16<DT>(yw[j]);
-        st[W + 2 * j + 1] += hi * hi16<DT>(yw[j]);
-      }
-    }
-    constexpr int NV = 2 * W;                      // 16 or 8
-    constexpr int HALVINGS = NV >= 16 ? 4 : 3;
-    butterfly16<NV, NV, 0>(st, fr);                // one total left per lane
-    int base = 0;
-#pragma unroll
-    for (int t = 0; t < HALVINGS; ++t) base += ((fr >> t) & 1) * (NV >> (t + 1));
-    if (HALVINGS == 4 || (fr >> 3) == 0) {
-      float* dst = p.stats + (size_t)(mt % p.stats_replicas) * 2 * p.Cout;
-      const int q = base / W, c = base % W;        // quantity (sum g / sum g*y), channel
-      if (cg + c < p.Cout) atomicAdd(dst + q * p.Cout + cg + c, st[0]);
-    }
+    for (int h = 0; h < HV; ++h)
+      if (co0 + h * W + cn < p.Cout) atomicAdd(dst + qn * p.Cout + co0 + h * W + cn, st[h]);
   }
 }
 

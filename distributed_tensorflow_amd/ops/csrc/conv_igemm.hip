@@ -131,13 +131,15 @@ void conv_igemm_kernel(const ConvParams p) {
   const int kvx = (tid & 3) ^ ((-(lrow >> 2)) & 3);            // logical K-chunk, pixel tile
   const int kvw = (tid & 3) ^ ((-(lrow / (4 * NR))) & 3);      // logical K-chunk, weight tile
   int xbase[XV];                   // POINTWISE: pixel row index; else pixel index base n*H*W
-  int xh[XV], xw[XV];              // base input coordinates (before the tap offset)
+  // base input coordinates (before the tap offset), two signed 16-bit halves of one register
+  // (row in the upper one): the tiles that run four waves per SIMD have no register to spare
+  int xhw[XV];
 #pragma unroll
   for (int r = 0; r < XV; ++r) {
     const int m = m0 + lrow + RPP * r;
     if (POINTWISE) {
       xbase[r] = (m < p.M) ? m : -1;
-      xh[r] = xw[r] = 0;
+      xhw[r] = 0;
     } else {
       if (m < p.M) {
         const uint32_t t = fd_div((uint32_t)m, p.divOW);
@@ -145,15 +147,15 @@ void conv_igemm_kernel(const ConvParams p) {
         const uint32_t n = fd_div(t, p.divOH);
         const int oh = (int)t - (int)n * p.OH;
         xbase[r] = (int)n * p.H * p.W;
-        xh[r] = oh * p.ISH + p.dh0;
-        xw[r] = ow * p.ISW + p.dw0;
+        xhw[r] = ((oh * p.ISH + p.dh0) << 16) | ((ow * p.ISW + p.dw0) & 0xffff);
       } else {
         xbase[r] = 0;
-        xh[r] = -(1 << 28);       // fails every bounds check
-        xw[r] = 0;
+        xhw[r] = (int)0xc0000000u;   // row -16384: fails every bounds check
       }
     }
   }
+  auto xh_of = [&](int r) { return xhw[r] >> 16; };
+  auto xw_of = [&](int r) { return (xhw[r] << 16) >> 16; };
   const T* __restrict__ gin = reinterpret_cast<const T*>(p.in);
   const T* __restrict__ gw = reinterpret_cast<const T*>(p.wgt);
   const T* zero_page = reinterpret_cast<const T*>(g_zero_page);
@@ -165,17 +167,18 @@ void conv_igemm_kernel(const ConvParams p) {
   // per load, recomputed when the wave-uniform tap (tli, tlj) changes --------------------
   const T* xptr[XV];
   const T* wptr[WV];
-  int xinc[XV], winc[WV];
+  uint32_t xlive = 0;              // bit r: pixel load r advances by a K-step (0: it sits on the zero page)
+  int winc[WV];
   int tli = 0, tlj = 0, tlc = 0;                   // current tap and K-steps done inside it
   const int steps_per_tap = p.Ctap / BK;
   auto setup_tap = [&]() {
 #pragma unroll
     for (int r = 0; r < XV; ++r) {
-      const int hi = xh[r] + tli * p.dhs;
-      const int wi = xw[r] + tlj * p.dws;
+      const int hi = xh_of(r) + tli * p.dhs;
+      const int wi = xw_of(r) + tlj * p.dws;
       const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
       xptr[r] = ok ? gin + ((size_t)(xbase[r] + hi * p.W + wi) * p.Cpix + kvx * EPC) : zero_page;
-      xinc[r] = ok ? BK : 0;
+      xlive = (xlive & ~(1u << r)) | ((ok ? 1u : 0u) << r);
     }
     const int wk = p.wk0 + tli * p.wsi + tlj * p.wsj + kvw * EPC;
 #pragma unroll
@@ -192,7 +195,7 @@ void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int r = 0; r < XV; ++r) {
       __builtin_amdgcn_global_load_lds((gptr_t)xptr[r], (lptr_t)(xs + r * (RPP * 64) + wave * 1024), 16, 0, 0);
-      xptr[r] += xinc[r];
+      xptr[r] += ((xlive >> r) & 1u) * BK;
     }
 #pragma unroll
     for (int r = 0; r < WV; ++r) {
@@ -227,8 +230,8 @@ void conv_igemm_kernel(const ConvParams p) {
         const bool ok = kvalx && xbase[r] >= 0;
         src = ok ? gin + ((size_t)xbase[r] * p.Cpix + kkx) : zero_page;
       } else {
-        const int hi = xh[r] + tix * p.dhs;
-        const int wi = xw[r] + tjx * p.dws;
+        const int hi = xh_of(r) + tix * p.dhs;
+        const int wi = xw_of(r) + tjx * p.dws;
         const bool ok = kvalx && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
         src = ok ? gin + ((size_t)(xbase[r] + hi * p.W + wi) * p.Cpix + kcx) : zero_page;
       }
@@ -441,6 +444,10 @@ void validate_conv_params(const ConvParams& p) {
   if (p.dt == DT_F32 && (p.scale || p.stats || p.relu))
     fail("fused statistics / folded BatchNorm epilogues exist for the 16-bit element types only");
   if (p.N <= 0 || p.H <= 0 || p.W <= 0 || p.OH <= 0 || p.OW <= 0) fail("bad spatial size");
+  // the kernels keep a pixel's base row / column as signed 16-bit halves of one register
+  if (p.H > 8192 || p.W > 8192 || p.dh0 < -4096 || p.dh0 > 4096 || p.dw0 < -4096 || p.dw0 > 4096 ||
+      (int64_t)(p.OH - 1) * p.ISH + p.dh0 > 12288 || (int64_t)(p.OW - 1) * p.ISW + p.dw0 > 12288)
+    fail("spatial coordinates beyond the 16-bit range of the gather");
   if (p.M != p.N * p.OH * p.OW) fail("M != N*OH*OW");
   if ((int64_t)p.N * p.H * p.W >= (1ll << 31) / 8) fail("input too large for 32-bit pixel index");
   if (p.Ctap % 8 || p.Ctap <= 0) fail("Ctap must be a positive multiple of 8");

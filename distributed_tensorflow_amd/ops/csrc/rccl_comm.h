@@ -10,9 +10,12 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
 #include <string>
+#include <thread>
 
 namespace dtf {
 
@@ -46,12 +49,43 @@ class RcclComm {
   static void group_start();
   static void group_end();
 
+  // All-link all-reduce for a full mesh of point-to-point links (xGMI inside a node: 7 links
+  // per GPU): every rank owns 1/size of the buffer.  Phase 1, one group of size - 1 sends and
+  // receives: rank r hands peer j its copy of shard j and receives j's copy of shard r into a
+  // scratch slot - every link carries one shard each way at the same time.  A kernel adds the
+  // size - 1 slots to the own shard.  Phase 2, a second group: the reduced shard goes to every
+  // peer and theirs come back into place.  A ring all-reduce pushes 2 (size - 1) / size of the
+  // buffer through ONE link per direction; this moves 2 / size of it through each of them.
+  // fp32 only (gradient buffers); count must be a multiple of size.  The scratch buffer
+  // ((size - 1) shards) is allocated at first use, so the first call must not be under capture.
+  void all_reduce_mesh(void* buf, size_t count, int dt, hipStream_t s);
+
+  // Failure handling.  RCCL reports a dead peer or a failed link asynchronously:
+  // `async_error` polls ncclCommGetAsyncError and returns "" while the communicator is
+  // healthy, else the error text - after aborting the communicator (ncclCommAbort), so that
+  // kernels blocked in a collective return and the process can exit instead of hanging.
+  std::string async_error();
+  void abort();
+  // Background poll every `interval_ms`: on an error the thread reports it on stderr, aborts the
+  // communicator and - with a non-zero `exit_code` - ends the process with that code (a launcher
+  // that watches its children then takes the whole job down: fail-fast instead of a hang).
+  void start_watchdog(int interval_ms, int exit_code);
+  void stop_watchdog();
+  bool failed() const { return failed_.load(); }
+
   size_t direct_min_bytes = 1 << 20;
   uint64_t collectives = 0;       // issued so far (tests, logs)
 
  private:
   void* comm_ = nullptr;
   int nranks_ = 1, rank_ = 0;
+  void* scratch_ = nullptr;
+  size_t scratch_bytes_ = 0;
+  std::mutex mutex_;              // abort / destroy against the watchdog
+  std::atomic<bool> failed_{false};
+  std::atomic<bool> stop_{false};
+  std::thread watchdog_;
+  std::string error_;
 };
 
 }  // namespace dtf

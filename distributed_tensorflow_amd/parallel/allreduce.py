@@ -15,6 +15,14 @@ Algorithms (`--all_reduce_alg`, reference `resnet_imagenet_main.py:116-117`):
   of the bucket between the two phases).
 * `hierarchical_copy`: reduce to rank 0, then broadcast - the single-root
   counterpart of TF's `HierarchicalCopyAllReduce`.
+* `mesh`: all-link exchange for a full mesh of point-to-point links (xGMI): every rank sends
+  peer j its copy of shard j and receives j's copy of its own shard - all peers at once -, adds
+  them up, then the reduced shards are exchanged the same way.  Each link carries 2/N of the
+  bucket; a ring pushes 2(N-1)/N of it through one link per direction.
+
+Data plane: the engine's own RCCL communicator (`parallel/rccl.py`, `--comm native`) whenever
+the job runs on RCCL, `torch.distributed` otherwise (gloo on the CPU) or on request
+(`--comm torch`).
 
 The reduction is a SUM of per-replica mean gradients; the division by the
 number of replicas is folded into the fused optimizer (`divisor`).
@@ -31,7 +39,7 @@ from .comm import Communicator
 
 __all__ = ["GradientReducer", "ALL_REDUCE_ALGS"]
 
-ALL_REDUCE_ALGS = (None, "nccl", "rccl", "ring", "hierarchical_copy")
+ALL_REDUCE_ALGS = (None, "nccl", "rccl", "ring", "hierarchical_copy", "mesh")
 
 
 def _priority_range(device):
@@ -45,11 +53,13 @@ def _priority_range(device):
 
 class GradientReducer:
   def __init__(self, comm: Communicator, store: ParamStore, buckets: List[Bucket],
-               alg: Optional[str] = None, group=None, group_size: Optional[int] = None):
+               alg: Optional[str] = None, group=None, group_size: Optional[int] = None,
+               comm_kind: Optional[str] = None):
     alg = alg.lower() if isinstance(alg, str) else alg
     if alg not in ALL_REDUCE_ALGS:
       raise ValueError("unknown all_reduce_alg %r (choose from nccl, ring, "
-                       "hierarchical_copy)" % (alg,))
+                       "hierarchical_copy, mesh)" % (alg,))
+    self.comm_kind = comm_kind     # "native" / "torch" / None: decided at first use
     self.comm = comm
     self.store = store
     self.buckets = buckets
@@ -118,13 +128,38 @@ class GradientReducer:
     return True
 
   def _native_comm(self):
-    """The engine's own RCCL communicator when `DTF_COMM=native` asks for it (GPU jobs)."""
+    """The engine's own RCCL communicator: the data plane of GPU jobs unless `--comm torch` /
+    `DTF_COMM=torch` asks for `torch.distributed` (`rccl.comm_choice`).  A sub-group reducer
+    keeps `torch.distributed` (the native communicator spans the whole job)."""
     if self._native is None:
       self._native = False
-      if os.environ.get("DTF_COMM", "torch") == "native" and self.comm.backend == "nccl":
-        from .rccl import get_native_comm  # pylint: disable=import-outside-toplevel
-        self._native = get_native_comm(self.comm) or False
+      from . import rccl  # pylint: disable=import-outside-toplevel
+      kind = rccl.comm_choice(self.comm.backend, self.store.grads.device.type, self.comm_kind)
+      if kind == "native" and self.group is None:
+        try:
+          self._native = rccl.get_native_comm(self.comm) or False
+        except Exception as e:  # pylint: disable=broad-except
+          if (self.comm_kind or os.environ.get("DTF_COMM", "")).lower() == "native":
+            raise
+          from ..utils import logging  # pylint: disable=import-outside-toplevel
+          logging.warning("native RCCL communicator unavailable (%s): gradient collectives go "
+                          "through torch.distributed", e)
+      self.comm_kind = "native" if self._native else "torch"
     return self._native or None
+
+  def describe(self) -> str:
+    """One line for the start-up log: data plane, algorithm, buckets, stream."""
+    nat = self._native_comm()
+    dev = self.store.grads.device
+    stream = "n/a"
+    if dev.type == "cuda":
+      cs = self._own_stream(dev)
+      stream = "own probed stream" if cs is not None else "compute stream position (single bucket)" \
+          if len(self.buckets) <= 1 else "torch.distributed's stream"
+    sizes = [(b.end - b.start) * 4 / 2 ** 20 for b in self.buckets]
+    return ("%s, alg %s, %d buckets (%s MB), collectives on: %s" % (
+        "native RCCL communicator" if nat is not None else "torch.distributed (%s)" % self.comm.backend,
+        self.alg, len(self.buckets), ", ".join("%.1f" % s for s in sizes), stream))
 
   def attach_to_plan(self, executor) -> bool:
     """Small-message policy, native communicator: the single bucket's all-reduce becomes the last
@@ -141,7 +176,8 @@ class GradientReducer:
     if nat is None:
       return False
     g = self._slice(self.buckets[0])
-    if executor.attach_collective(nat.plan_entry(g, "direct" if self.alg == "ring" else "auto")):
+    if executor.attach_collective(nat.plan_entry(
+        g, {"ring": "direct", "mesh": "mesh"}.get(self.alg, "auto"))):
       self._in_plan.add(executor)
       return True
     return False
@@ -158,9 +194,12 @@ class GradientReducer:
         nat.broadcast(g, 0)
         self.collectives_launched += 2
       else:
-        nat.all_reduce(g, "direct" if self.alg == "ring" else "auto")
+        nat.all_reduce(g, {"ring": "direct", "mesh": "mesh"}.get(self.alg, "auto"))
         self.collectives_launched += 1
       return None
+    if self.alg == "mesh" and g.numel() % self.n == 0 and self.n > 1:
+      self.collectives_launched += 2
+      return self._mesh(g)
     if self.alg == "ring" and c.supports_reduce_scatter() and g.numel() % self.n == 0:
       shard = g.numel() // self.n
       r = c.rank if self.group is None else torch.distributed.get_rank(self.group)
@@ -215,8 +254,39 @@ class GradientReducer:
     else:
       self._pending.append(self._issue(g, async_op=True))
 
+  def _mesh(self, g: torch.Tensor):
+    """The all-link exchange over `torch.distributed` point-to-point calls (the native
+    communicator runs the same schedule from C++, `RcclComm::all_reduce_mesh`): blocking."""
+    import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+    n = self.n
+    ranks = list(range(n)) if self.group is None else dist.get_process_group_ranks(self.group)
+    me = ranks.index(self.comm.rank)
+    shard = g.numel() // n
+    scratch = torch.empty((n - 1, shard), dtype=g.dtype, device=g.device)
+    ops = []
+    for j in range(n):
+      if j == me:
+        continue
+      slot = j if j < me else j - 1
+      ops.append(dist.P2POp(dist.isend, g[j * shard:(j + 1) * shard], ranks[j], self.group))
+      ops.append(dist.P2POp(dist.irecv, scratch[slot], ranks[j], self.group))
+    for w in dist.batch_isend_irecv(ops):
+      w.wait()
+    own = g[me * shard:(me + 1) * shard]
+    own.add_(scratch.sum(0))
+    ops = []
+    for j in range(n):
+      if j == me:
+        continue
+      ops.append(dist.P2POp(dist.isend, own, ranks[j], self.group))
+      ops.append(dist.P2POp(dist.irecv, g[j * shard:(j + 1) * shard], ranks[j], self.group))
+    for w in dist.batch_isend_irecv(ops):
+      w.wait()
+    return None
+
   def finish(self):
-    """Orders the optimizer after every outstanding collective."""
+    """Orders the optimizer after every outstanding collective; once per step this is also where
+    an asynchronous RCCL error surfaces (the watchdog thread catches it between steps)."""
     for w in self._pending:
       if w is not None:
         w.wait()
@@ -224,6 +294,8 @@ class GradientReducer:
     if self._stream_pending:
       torch.cuda.current_stream(self._stream.device).wait_stream(self._stream)
       self._stream_pending = False
+    if self._native:
+      self._native.check()
 
   def reduce_all_now(self):
     """Non-overlapped path: reduce every bucket after backward has finished."""

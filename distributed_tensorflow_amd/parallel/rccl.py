@@ -1,12 +1,21 @@
 """The engine's own RCCL communicator (`ops/csrc/rccl_comm.cpp`) behind a small Python handle.
 
-`torch.distributed` stays the default data plane (`parallel/comm.py`); this communicator is the
-C++ alternative for the gradient collectives (`DTF_COMM=native`): the calls are issued from the
-extension on a HIP stream handle, can be recorded as launch-plan entries (op kind `allreduce`)
-and are therefore captured into the step's hipGraph, and the algorithm is chosen by message size -
-one-shot `ncclAllReduce` for latency-bound buckets (all of ResNet-56 is 3.4 MB), reduce-scatter +
-all-gather for large ones: xGMI is a full mesh of point-to-point links (7 x ~153 GB/s per GPU), a
-ring drives one link per direction while the direct exchange of 1/N shards uses all of them.
+This is the data plane of GPU jobs (`--comm native`, the default when the job runs on RCCL;
+`--comm torch` / `DTF_COMM=torch` selects `torch.distributed`, `parallel/comm.py`, which also
+stays the control plane: rendezvous store, barriers, scalar reductions).  Calls are issued from
+the extension on a HIP stream handle, can be recorded as launch-plan entries (op kind
+`allreduce`) and are therefore captured into the step's hipGraph.  Algorithms: `oneshot`
+(`ncclAllReduce`, RCCL picks ring / tree / direct itself: the default), `direct` (reduce-scatter
++ all-gather, `--all_reduce_alg ring`) and `mesh` (`--all_reduce_alg mesh`): an all-link
+exchange written for xGMI's full mesh of point-to-point links (7 x ~153 GB/s per GPU) - grouped
+sends / receives move 1/N shards over every link at once, where a ring drives one link per
+direction.  The parameter server's push / pull transfers use `send` / `recv` on two further
+communicators, one per direction (`parallel/parameter_server.py`).
+
+Failures: a watchdog thread polls `ncclCommGetAsyncError` once a second; on an error it aborts
+the communicator (`ncclCommAbort`, so kernels blocked in a collective return) and ends the
+process with exit code 70, which the launcher turns into the end of the whole job
+(`launch.py`).  `check()` is the same poll on the caller's thread, once per step.
 
 The 128-byte unique id travels through the rendezvous store of the process group that is already
 up (the reference bootstraps its transports from `TF_CONFIG` the same way: gRPC server start-up,
@@ -36,7 +45,8 @@ def _rccl_library() -> str:
 class NativeComm:
   DT = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
 
-  def __init__(self, rank: int, world_size: int, store=None, device: Optional[torch.device] = None):
+  def __init__(self, rank: int, world_size: int, store=None, device: Optional[torch.device] = None,
+               watchdog: bool = True):
     from ..ops import native  # pylint: disable=import-outside-toplevel
     global _SEQ
     ext = native.ext()
@@ -56,11 +66,24 @@ class NativeComm:
       else:
         uid = bytes(store.get(key))
       self._c = ext.RcclComm(uid, self.world_size, self.rank)
+    # `auto` = RCCL's own all-reduce unless a threshold asks for reduce-scatter + all-gather
     min_mb = os.environ.get("DTF_ALLREDUCE_DIRECT_MIN_MB")
-    if min_mb is not None:
-      self._c.direct_min_bytes = int(float(min_mb) * (1 << 20))
-    logging.info("native RCCL communicator: rank %d / %d, direct all-reduce from %d bytes",
-                 self.rank, self.world_size, self._c.direct_min_bytes)
+    self._c.direct_min_bytes = int(float(min_mb) * (1 << 20)) if min_mb is not None else 1 << 62
+    if watchdog and os.environ.get("DTF_COMM_WATCHDOG", "1") != "0":
+      self._c.start_watchdog(int(os.environ.get("DTF_COMM_WATCHDOG_MS", "1000")), self.EXIT_CODE)
+    logging.info("native RCCL communicator: rank %d / %d%s", self.rank, self.world_size,
+                 ", watchdog on" if watchdog else "")
+
+  EXIT_CODE = 70        # EX_SOFTWARE: what a rank exits with when its communicator failed
+
+  def check(self):
+    """Raises when RCCL has reported an asynchronous error (the communicator is aborted by then)."""
+    err = self._c.async_error()
+    if err:
+      raise RuntimeError(err)
+
+  def close(self):
+    self._c.stop_watchdog()
 
   @property
   def handle(self) -> int:
@@ -85,8 +108,24 @@ class NativeComm:
       self._c.all_reduce(p, n, dt, s)
     elif mode == "direct" and n % self.world_size == 0:
       self._c.all_reduce_direct(p, n, dt, s)
+    elif mode == "mesh" and n % self.world_size == 0 and dt == 2:
+      self._c.all_reduce_mesh(p, n, dt, s)
     else:
       self._c.all_reduce_auto(p, n, dt, s)
+
+  # -- point to point (parameter server) ----------------------------------------------------
+  def send(self, t: torch.Tensor, peer: int, stream=None):
+    p, n, dt, s = self._args(t, stream)
+    self._c.send(p, n, dt, int(peer), s)
+
+  def recv(self, t: torch.Tensor, peer: int, stream=None):
+    p, n, dt, s = self._args(t, stream)
+    self._c.recv(p, n, dt, int(peer), s)
+
+  def group(self):
+    """Context manager: the sends / receives issued inside form one RCCL group (they progress
+    together; a send and the matching receive of one rank to itself must share a group)."""
+    return _Group(self._c)
 
   def broadcast(self, t: torch.Tensor, root: int = 0, stream=None):
     p, n, dt, s = self._args(t, stream)
@@ -99,8 +138,23 @@ class NativeComm:
   def plan_entry(self, t: torch.Tensor, mode: str = "auto") -> dict:
     """Descriptor of an `allreduce` launch-plan entry for `t` (captured with the plan)."""
     p, n, dt, _ = self._args(t, 0)
+    if mode == "mesh" and (n % self.world_size or dt != 2):
+      mode = "auto"
     return dict(comm=self.handle, buf=p, count=n, dt=dt,
-                mode={"oneshot": 0, "direct": 1, "auto": 2}[mode])
+                mode={"oneshot": 0, "direct": 1, "auto": 2, "mesh": 3}[mode])
+
+
+class _Group:
+  def __init__(self, c):
+    self._c = c
+
+  def __enter__(self):
+    self._c.group_start()
+    return self
+
+  def __exit__(self, *exc):
+    self._c.group_end()
+    return False
 
 
 def get_native_comm(comm) -> Optional[NativeComm]:
@@ -114,3 +168,30 @@ def get_native_comm(comm) -> Optional[NativeComm]:
     _NATIVE = NativeComm(comm.rank, comm.world_size, store if comm.world_size > 1 else None,
                          comm.device)
   return _NATIVE
+
+
+def new_native_comm(comm, watchdog: bool = True) -> NativeComm:
+  """A further communicator over the ranks of `comm` (COLLECTIVE: every rank calls it, in the
+  same order): the parameter server keeps one per transfer direction, each with its own stream,
+  so that a receive waiting for its sender never holds up traffic the other way."""
+  store = comm.store() if comm.world_size > 1 else None
+  return NativeComm(comm.rank, comm.world_size, store, comm.device, watchdog=watchdog)
+
+
+def comm_choice(backend: str, device_type: str, requested: Optional[str] = None) -> str:
+  """`native` or `torch` for the gradient collectives of a job: what `--comm` / `DTF_COMM` ask
+  for, else the engine's communicator whenever the job runs on RCCL with the extension built."""
+  want = (requested or os.environ.get("DTF_COMM") or "auto").lower()
+  if want not in ("auto", "native", "torch"):
+    raise ValueError("--comm must be native, torch or auto (got %r)" % want)
+  if backend != "nccl" or device_type != "cuda":
+    return "torch"
+  if want == "torch":
+    return "torch"
+  from ..ops import native  # pylint: disable=import-outside-toplevel
+  if not native.available():
+    if want == "native":
+      raise RuntimeError("--comm native needs the in-tree extension (python -m "
+                         "distributed_tensorflow_amd.ops.build)")
+    return "torch"
+  return "native"

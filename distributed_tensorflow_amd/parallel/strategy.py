@@ -116,12 +116,13 @@ class MirroredStrategy(Strategy):
 
   def __init__(self, task: Optional[TaskInfo] = None, use_gpu: bool = True,
                all_reduce_alg: Optional[str] = None, num_packs: int = 1,
-               bucket_bytes: Optional[int] = None):
+               bucket_bytes: Optional[int] = None, comm_kind: Optional[str] = None):
     task = task or resolve_task()
     comm = get_communicator(task, use_gpu=use_gpu)
     super().__init__(comm.device)
     self.comm = comm
     self.task = task
+    self.comm_kind = comm_kind           # `--comm`: native / torch / None (auto)
     self.all_reduce_alg = all_reduce_alg
     self.num_packs = num_packs
     self.bucket_bytes = bucket_bytes
@@ -141,7 +142,8 @@ class MirroredStrategy(Strategy):
   def make_reducer(self, store, buckets):
     if self.comm.world_size <= 1 and not self.comm.rehearse:
       return None
-    return GradientReducer(self.comm, store, buckets, self.all_reduce_alg)
+    return GradientReducer(self.comm, store, buckets, self.all_reduce_alg,
+                           comm_kind=self.comm_kind)
 
   def broadcast_variables(self, store, root: int = 0):
     if self.comm.world_size <= 1 and not self.comm.rehearse:
@@ -189,7 +191,7 @@ def strategy_needs_launch(distribution_strategy: str, num_gpus: int) -> int:
 
 
 def get_distribution_strategy(distribution_strategy="default", num_gpus=0, num_workers=1,
-                              all_reduce_alg=None, num_packs=1, bucket_bytes=None):
+                              all_reduce_alg=None, num_packs=1, bucket_bytes=None, comm_kind=None):
   """Returns a strategy object, or None for `off`.
 
   Args mirror the reference helper.  `num_gpus` is GPUs *per worker*; 0 runs on the
@@ -208,7 +210,8 @@ def get_distribution_strategy(distribution_strategy="default", num_gpus=0, num_w
 
   if ds == "multi_worker_mirrored":
     task = resolve_task(gpus_per_task=max(num_gpus, 1))
-    return MultiWorkerMirroredStrategy(task, use_gpu, all_reduce_alg, num_packs, bucket_bytes)
+    return MultiWorkerMirroredStrategy(task, use_gpu, all_reduce_alg, num_packs, bucket_bytes,
+                                       comm_kind)
 
   if ds == "one_device" or (ds == "default" and num_gpus <= 1):
     if num_gpus > 1:
@@ -219,11 +222,11 @@ def get_distribution_strategy(distribution_strategy="default", num_gpus=0, num_w
 
   if ds in ("mirrored", "default"):
     task = resolve_task(gpus_per_task=max(num_gpus, 1))
-    if all_reduce_alg not in (None, "nccl", "hierarchical_copy", "ring"):
+    if all_reduce_alg not in (None, "nccl", "hierarchical_copy", "ring", "mesh"):
       raise ValueError("When used with `mirrored`, valid values for all_reduce_alg are "
-                       "['nccl', 'hierarchical_copy', 'ring']. Supplied value: {}"
+                       "['nccl', 'hierarchical_copy', 'ring', 'mesh']. Supplied value: {}"
                        .format(all_reduce_alg))
-    return MirroredStrategy(task, use_gpu, all_reduce_alg, num_packs, bucket_bytes)
+    return MirroredStrategy(task, use_gpu, all_reduce_alg, num_packs, bucket_bytes, comm_kind)
 
   if ds == "parameter_server":
     from .parameter_server import ParameterServerStrategy  # pylint: disable=import-outside-toplevel

@@ -122,7 +122,7 @@ def _make_strategy(flags_obj, use_horovod: bool):
       distribution_strategy=flags_obj.distribution_strategy,
       num_gpus=flags_obj.num_gpus, num_workers=num_workers,
       all_reduce_alg=flags_obj.all_reduce_alg, num_packs=flags_obj.num_packs,
-      bucket_bytes=bucket_bytes)
+      bucket_bytes=bucket_bytes, comm_kind=getattr(flags_obj, "comm", None))
   return strategy, num_workers
 
 
@@ -285,6 +285,11 @@ def run_classifier(flags_obj, cfg: DatasetConfig, use_horovod: bool = False):
     verbose = 1 if strategy.is_chief else 2
   elif strategy is not None and not strategy.is_chief:
     verbose = 0
+
+  # effective environment, process group, reducer and launch mode, once, from the first rank
+  from ..utils.runtime_report import log_runtime_report  # pylint: disable=import-outside-toplevel
+  log_runtime_report(strategy, None if is_ps else model,
+                     rank=(hvd.rank() if hvd is not None else None))
 
   history = model.fit(train_input_dataset, epochs=train_epochs,
                       steps_per_epoch=steps_per_epoch, callbacks=callbacks,

@@ -356,7 +356,8 @@ def define_performance(num_parallel_calls=False, inter_op=True, intra_op=True,
     DEFINE_string("all_reduce_alg", None,
                   "Gradient all-reduce algorithm: nccl (RCCL all-reduce per fusion bucket), "
                   "ring (reduce-scatter + all-gather), hierarchical_copy (reduce to rank 0 "
-                  "then broadcast). Default: nccl.", "ara")
+                  "then broadcast), mesh (all-link shard exchange over the point-to-point "
+                  "xGMI links). Default: nccl.", "ara")
   if num_packs:
     DEFINE_integer("num_packs", 1,
                    "Number of fusion buckets the gradients are packed into for the "

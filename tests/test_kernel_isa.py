@@ -110,3 +110,32 @@ def test_pipeline_kernels_keep_loads_in_flight(tmp_path):
       # one wait per distinct depth of the drain ladder, nothing else
       assert len(waits) <= stages, "%s: unexpected vector-memory waits in the loop: %s" % (name, waits)
   assert deep >= 8
+
+
+@pytest.mark.parametrize("obj", ["conv_igemm.o", "conv_pipe.o", "conv_halo.o", "conv_wgrad.o"])
+def test_no_convolution_kernel_spills_registers(obj, tmp_path):
+  """Every instantiation of the convolution kernels fits its register budget: no scratch memory
+  and no spilled vector register in the code object's kernel metadata.  (A fused epilogue that
+  overflowed the 128 registers of the four-waves-per-SIMD tiles once spilled 72 - 91 of them to
+  scratch and made the fusion slower than the sweep it replaced.)"""
+  path = os.path.join(BUILD, obj)
+  if not os.path.exists(path):
+    from distributed_tensorflow_amd.ops import build
+    build.build(verbose=False)
+  fb, co = str(tmp_path / "fatbin"), str(tmp_path / "code.co")
+  subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fb, path,
+                  str(tmp_path / "stripped.o")], check=True)
+  subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", "--unbundle",
+                  "--input=" + fb, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co],
+                 check=True)
+  notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True,
+                         capture_output=True, text=True).stdout
+  kernels = notes.split("- .agpr_count:")[1:]
+  assert len(kernels) >= 8
+  bad = []
+  for k in kernels:
+    scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", k).group(1))
+    spilled = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", k).group(1))
+    if scratch or spilled:
+      bad.append((re.search(r"\.name:\s+(\S+)", k).group(1), scratch, spilled))
+  assert not bad, "%d kernels of %s use scratch: %s" % (len(bad), obj, bad[:4])
