@@ -24,11 +24,17 @@ Requests:
 * `pull:<rank>:<fmt>[:fresh]` - PS -> worker: the parameter shard as fp32 or bfloat16
   (a 16-bit worker would round the fp32 values the same way itself; half the
   bytes), PS 0 also the BatchNorm moving statistics.
-* `push:<rank>:<lr>:<divisor>:<fmt>:<lo>-<hi>,...` - worker -> PS: the gradient
-  shard as pieces (one per gradient bucket that intersects the shard, in the
-  order the backward pass completes them), fp32 or bfloat16; to PS 0 also the
-  moving statistics; last a one-element trailer: 1 = apply, 0 = the worker found
-  a non-finite gradient (dynamic loss scaling), drop it.
+* `push:<rank>:<lr>:<divisor>:<fmt>:<lo>-<hi>,...` - worker -> PS, protocol `stream`: the
+  whole push announced before the backward pass; the gradient shard follows as pieces (one per
+  gradient bucket that intersects the shard, in the order the backward pass completes them),
+  fp32 or bfloat16; to PS 0 also the moving statistics; last a two-element trailer
+  `[skip, factor]`: skip != 0 - the worker found a non-finite gradient (dynamic loss scaling),
+  drop the push; factor multiplies the gradients (1 / loss scale when the scale lives on the
+  worker's GPU).
+* `piece:<rank>:<fmt>:<lo>-<hi>` and `commit:<rank>:<lr>:<divisor>:<fmt>` - protocol `pieces`:
+  a bucket is announced when it is *ready to leave* (its kernels have finished), so a PS only
+  ever posts a receive whose data is already waiting at the sender; `commit` closes the push:
+  moving statistics (PS 0) and the trailer follow, and the PS applies it.
 * `done:<rank>` - the worker is finished; a PS returns once every worker said so
   (a clean shutdown instead of `pkill`).
 
@@ -43,12 +49,16 @@ so that the host thread only enqueues: the next parameters arrive while this
 step computes (they miss this step's own update: staleness + 1, on top of the
 staleness asynchronous SGD has anyway; `DTF_PS_PREFETCH=0` restores strict
 pull -> compute -> push), and all but the last bucket of the push is hidden
-behind the backward pass.  The PS posts the receives of a push and moves on: up
-to two pushes are in flight into two buffers while it serves other requests, and
-a complete push is applied with one fused SGD-momentum+L2 launch over the shard.
-With RCCL a posted receive occupies the communicator's stream, so there a worker
-announces its push only when the whole gradient is ready and the PS completes
-each push before it takes the next request.
+behind the backward pass.
+
+Data planes (`ps_transport.py`).  Over gloo (`stream` protocol) the PS posts the receives of a
+whole push and moves on: up to two pushes are in flight into two buffers while it serves other
+requests.  Over RCCL a posted receive is a kernel that occupies its stream until the sender
+shows up, so the RCCL plane keeps one communicator and stream per direction and runs the
+`pieces` protocol: nothing is posted before its data exists, every worker lands in a buffer of
+its own, and the PS side is stream-ordered end to end - receive, fused SGD-momentum+L2 over the
+shard with the trailer read *on the device* (no host synchronisation per push), the cast of the
+next pull behind the update - so its request loop never waits for the GPU.
 """
 from __future__ import annotations
 
@@ -64,6 +74,7 @@ import torch
 from ..utils import logging
 from .cluster import TaskInfo, resolve_task
 from .comm import Communicator, get_communicator
+from .ps_transport import PULL, PUSH, make_plane
 from .strategy import Strategy
 
 __all__ = ["ParameterServerStrategy", "shard_ranges"]
@@ -86,7 +97,7 @@ class ParameterServerStrategy(Strategy):
   synchronous = False
 
   def __init__(self, task: Optional[TaskInfo] = None, use_gpu: bool = True,
-               poll_timeout_s: float = 1800.0):
+               poll_timeout_s: float = 1800.0, comm_kind: Optional[str] = None):
     task = task or resolve_task(gpus_per_task=1)
     if task.num_ps < 1:
       raise ValueError("parameter_server strategy needs at least one 'ps' task in the "
@@ -116,8 +127,29 @@ class ParameterServerStrategy(Strategy):
     self.bucket_bytes = int(float(os.environ.get("DTF_PS_BUCKET_MB", "16")) * (1 << 20))
     # gradients travel as bfloat16 when the worker computes in a 16-bit type, unless told otherwise
     self.push_dtype = os.environ.get("DTF_PS_PUSH_DTYPE", "auto").lower()
-    # a posted receive is free with gloo and blocks the communicator's stream with RCCL
-    self.stream_push = comm.backend != "nccl" and os.environ.get("DTF_PS_STREAM_PUSH", "1") != "0"
+    # The data plane (COLLECTIVE: every rank builds it here).  gloo moves one message with one
+    # progress thread per process group (2.5 GB/s on the test host, and no faster in both
+    # directions at once), so its transfers are striped over several groups, half of them for
+    # each direction (51 MB each way: 40.7 -> 20.5 ms with 4); the RCCL plane has a communicator
+    # and a stream per direction.
+    probe = None
+    if comm.device.type == "cuda" and task.job != "ps":
+      probe = torch.cuda.default_stream(comm.device)
+    self.plane = make_plane(comm, comm_kind, probe_against=probe)
+    # `pieces`: buckets are announced when they are ready to leave (the only protocol in which a
+    # PS never posts a receive that has to wait: required by RCCL, optional elsewhere);
+    # `stream`: the whole push is announced up front and the PS keeps two pushes in flight
+    # (gloo); `whole`: one announcement after the step (torch.distributed on RCCL).
+    default = "pieces" if self.plane.device_side else \
+        ("stream" if comm.backend != "nccl" else "whole")
+    self.protocol = os.environ.get("DTF_PS_PROTOCOL", default).lower()
+    if self.protocol not in ("pieces", "stream", "whole"):
+      raise ValueError("DTF_PS_PROTOCOL must be pieces, stream or whole")
+    if self.plane.device_side and self.protocol != "pieces":
+      raise ValueError("the RCCL data plane runs the `pieces` protocol")
+    if os.environ.get("DTF_PS_STREAM_PUSH", "1") == "0" and self.protocol == "stream":
+      self.protocol = "whole"
+    self.stream_push = self.protocol == "stream"
     self._recv_lane = concurrent.futures.ThreadPoolExecutor(1, thread_name_prefix="ps-recv")
     self._send_lane = concurrent.futures.ThreadPoolExecutor(1, thread_name_prefix="ps-send")
     self._prefetched = None        # (future, fmt) of the parameters requested ahead
@@ -126,20 +158,15 @@ class ParameterServerStrategy(Strategy):
     self._copy_stream = None
     self._executor = None          # set by orders_side_lane()
     self._h2d_done = None
-    # gloo moves one message with one progress thread per process group (2.5 GB/s on the test
-    # host, and no faster in both directions at once); transfers are therefore striped over
-    # several groups, half of them for each direction (51 MB each way: 40.7 -> 20.5 ms with 4)
-    nch = int(os.environ.get("DTF_PS_CHANNELS", "1" if comm.backend == "nccl" else "4"))
-    self._channels: List[List] = [[None], [None]]      # per direction: process groups
-    if comm.world_size > 1 and nch > 1:
-      import torch.distributed as dist  # pylint: disable=import-outside-toplevel
-      groups = [dist.new_group(ranks=list(range(comm.world_size)), backend=comm.backend)
-                for _ in range(nch)]
-      self._channels = [groups[0::2], groups[1::2]]
     # seconds the training thread spent waiting for transfers: what is *not* hidden
     self.wait_s = {"pull": 0.0, "push": 0.0, "steps": 0, "gpu_ms": 0.0, "host_s": 0.0}
     self._step_events = None
     self._t_begin = None
+
+  def describe(self) -> str:
+    return "%d ps + %d workers, data plane: %s, protocol %s, push buckets %.0f MB, prefetch %s" % (
+        self.num_ps, self.num_workers, self.plane.describe(), self.protocol,
+        self.bucket_bytes / 2 ** 20, "on" if self.prefetch else "off")
 
   # -- topology --------------------------------------------------------------------
   @property
@@ -194,27 +221,14 @@ class ParameterServerStrategy(Strategy):
     except Exception:  # pragma: no cover - a store without check(): behave as if busy
       return True
 
-  # -- striped transfers ---------------------------------------------------------------
-  STRIPE_MIN = 1 << 17           # elements: smaller messages travel whole on the first channel
-
-  def _stripes(self, t: torch.Tensor, direction: int):
-    groups = self._channels[direction]
-    n = t.numel()
-    if len(groups) == 1 or n < self.STRIPE_MIN:
-      return [(t, groups[0])]
-    per = -(-n // len(groups))
-    per = -(-per // 8) * 8
-    return [(t[i * per:min(n, (i + 1) * per)], g) for i, g in enumerate(groups) if i * per < n]
-
+  # -- transfers (see ps_transport.py) ------------------------------------------------------------
   def _isend(self, t: torch.Tensor, dst: int, direction: int) -> List:
-    import torch.distributed as dist  # pylint: disable=import-outside-toplevel
-    return [dist.isend(c, dst, group=g) for c, g in self._stripes(t, direction)]
+    return self.plane.isend(t, dst, direction)
 
   def _irecv(self, t: torch.Tensor, src: int, direction: int) -> List:
-    import torch.distributed as dist  # pylint: disable=import-outside-toplevel
-    return [dist.irecv(c, src, group=g) for c, g in self._stripes(t, direction)]
+    return self.plane.irecv(t, src, direction)
 
-  PULL, PUSH = 0, 1              # directions: PS -> worker, worker -> PS
+  PULL, PUSH = PULL, PUSH        # directions: PS -> worker, worker -> PS
 
   # -- buffers -----------------------------------------------------------------------
   # RCCL moves device memory directly.  Any other backend (gloo: parameter server in host
@@ -222,7 +236,7 @@ class ParameterServerStrategy(Strategy):
   # gets device tensors staged through pinned host buffers here: gloo's own handling of device
   # tensors took seconds for the 102 MB of ResNet-50 on the test machine.
   def _staged(self, device) -> bool:
-    return torch.device(device).type == "cuda" and self.comm.backend != "nccl"
+    return self.plane.staged(device)
 
   def _buf(self, tag, n: int, dtype, device=None, pinned=False) -> torch.Tensor:
     key = (tag, n, dtype, str(device), pinned)
@@ -282,7 +296,11 @@ class ParameterServerStrategy(Strategy):
       if dev.type == "cuda":
         torch.cuda.set_device(dev)
       if consumed is not None:
-        consumed.synchronize()       # the previous pull has been copied out of the landing buffers
+        # the previous pull has been copied out of the landing buffers before they are refilled
+        if self.plane.device_side:
+          self.plane.order_after(self.PULL, consumed)
+        else:
+          consumed.synchronize()
       out = []
       for k, (a, b) in enumerate(shards):
         land, works = None, []
@@ -339,7 +357,7 @@ class ParameterServerStrategy(Strategy):
         store.params[a:b].copy_(land[:b - a])       # device to device, widening bf16
       if state is not None:
         store.state.copy_(state[:store.num_state_elements], non_blocking=True)
-    if self._staged(dev):
+    if dev.type == "cuda":
       self._h2d_done = torch.cuda.Event()
       self._h2d_done.record()
     store.version += 1
@@ -402,7 +420,7 @@ class ParameterServerStrategy(Strategy):
     while p["next"] < len(p["order"]) and p["order"][p["next"]].index in p["ready"]:
       bk = p["order"][p["next"]]
       p["next"] += 1
-      if self.stream_push:
+      if self.protocol in ("stream", "pieces"):
         self._queue_bucket(p, bk, p["ready"][bk.index])
 
   def _queue_bucket(self, p, bk, ev):
@@ -412,6 +430,12 @@ class ParameterServerStrategy(Strategy):
     dtype = torch.bfloat16 if fmt == "bf16" else torch.float32
     shards = self._shards(store)
     n = store.num_elements
+    pieces = self.protocol == "pieces"
+    device_side = self.plane.device_side
+
+    def announce(k, a, lo, hi):
+      if pieces:              # the data is ready: the PS may post its receive without waiting
+        self._post(k, "piece:%d:%s:%d-%d" % (self.comm.rank, fmt, lo - a, hi - a))
 
     def task():
       src = store.grads
@@ -429,10 +453,14 @@ class ParameterServerStrategy(Strategy):
             host = self._buf("push_host", n, dtype, None, pinned=True)
             host[bk.start:bk.end].copy_(src[bk.start:bk.end], non_blocking=True)
             src = host
-            stream.synchronize()
+          if staged or pieces:
+            stream.synchronize()          # the bucket (and its 16-bit copy) exist: announce it
+          if device_side:
+            self.plane.order_after(self.PUSH, stream)
           for k, (a, b) in enumerate(shards):
             lo, hi = max(a, bk.start), min(b, bk.end)
             if hi > lo:
+              announce(k, a, lo, hi)
               p["works"] += self._isend(src[lo:hi], k, self.PUSH)
         return
       if fmt == "bf16":
@@ -441,18 +469,22 @@ class ParameterServerStrategy(Strategy):
         for k, (a, b) in enumerate(shards):
           lo, hi = max(a, bk.start), min(b, bk.end)
           if hi > lo:
+            announce(k, a, lo, hi)
             p["works"] += self._isend(src[lo - bk.start:hi - bk.start], k, self.PUSH)
         return
       for k, (a, b) in enumerate(shards):
         lo, hi = max(a, bk.start), min(b, bk.end)
         if hi > lo:
+          announce(k, a, lo, hi)
           p["works"] += self._isend(src[lo:hi], k, self.PUSH)
 
     self._last_send = self._send_lane.submit(task)
 
-  def end_push(self, finite: bool = True):
+  def end_push(self, finite: bool = True, trailer: Optional[torch.Tensor] = None):
     """After the step: whatever has not left yet, the moving statistics (to PS 0) and the
-    trailer that tells every PS whether to apply this push."""
+    trailer `[skip, factor]` that tells every PS whether to apply this push and what to multiply
+    the gradients by.  `trailer`: two floats on the worker's device, written by the device-side
+    loss-scale kernel (the host never learns whether the step was finite); else `finite` says it."""
     p = self._push
     store = p["store"]
     dev = store.device
@@ -463,11 +495,16 @@ class ParameterServerStrategy(Strategy):
       if side is not None:
         # the executor skipped its joins: the step ends when the weight-gradient lane has
         torch.cuda.current_stream(dev).wait_stream(side)
+      if self.plane.device_side and store.num_state_elements:
+        # the moving statistics as they are now: the next step's forward pass updates them
+        # while this push may still be waiting for its turn
+        snap = self._buf("push_state_dev", store.num_state_elements, torch.float32, dev)
+        snap.copy_(store.state)
       ev = [torch.cuda.Event()]
       ev[0].record()
       self._step_events[1].record()
-    if not self.stream_push:
-      self._post_push()                       # RCCL: announced only now, sent in one go
+    if self.protocol == "whole":
+      self._post_push()                       # announced only now, sent in one go
       for bk in p["order"]:
         self._queue_bucket(p, bk, ev)
     else:
@@ -475,30 +512,42 @@ class ParameterServerStrategy(Strategy):
         self._queue_bucket(p, p["order"][p["next"]], ev)
         p["next"] += 1
     staged = self._staged(dev)
-    flag = 1.0 if finite else 0.0
+    device_side = self.plane.device_side
+    pieces = self.protocol == "pieces"
+    if trailer is None:
+      trailer = torch.tensor([0.0 if finite else 1.0, 1.0], dtype=torch.float32,
+                             device="cpu" if (staged or dev.type != "cuda") else dev)
 
     def task():
       state = store.state
-      trailer = torch.full((1,), flag, dtype=torch.float32, device="cpu" if staged else dev)
+      if device_side and store.num_state_elements:
+        state = self._buf("push_state_dev", store.num_state_elements, torch.float32, dev)
+      tr = trailer
       if dev.type == "cuda":
         torch.cuda.set_device(dev)
         for e in ev or []:
           e.synchronize()
-        if staged and store.num_state_elements:
-          host = self._buf("push_state", store.num_state_elements, torch.float32, None, pinned=True)
-          host.copy_(store.state)
-          state = host
+        if staged:
+          tr = trailer.cpu()
+          if store.num_state_elements:
+            host = self._buf("push_state", store.num_state_elements, torch.float32, None, pinned=True)
+            host.copy_(store.state)
+            state = host
       works = p["works"]
       for k in range(self.num_ps):
+        if pieces:
+          self._post(k, "commit:%d:%r:%r:%s" % (self.comm.rank, p["lr"], p["divisor"], p["fmt"]))
         if k == 0 and store.num_state_elements:
           works += self._isend(state[:store.num_state_elements], 0, self.PUSH)
-        works += self._isend(trailer, k, self.PUSH)
+        works += self._isend(tr, k, self.PUSH)
       # The sends to different PS ranks are independent of each other (none of them is waited
       # for before all are posted): a PS that is busy completing another worker's push cannot
       # hold up what this worker owes to the other PS ranks, which rules out a cycle of waits
       # across several PS ranks and workers.
       for w in works:
         w.wait()
+      if device_side:
+        self.plane.check()
       p["keep"].clear()
 
     self._last_send = self._send_lane.submit(task)
@@ -516,6 +565,11 @@ class ParameterServerStrategy(Strategy):
       self.prefetch = keep
     self.end_push(finite)
     self._last_send.result()
+
+  def side_lane(self):
+    """The stream of the executor's weight-gradient lane when the pushes order themselves behind
+    it (`orders_side_lane`), else None."""
+    return self._executor.side_stream() if self._executor is not None else None
 
   def shutdown(self):
     if self.is_ps_task or self._done_sent or self._store is None:
@@ -545,6 +599,7 @@ class ParameterServerStrategy(Strategy):
     n = b - a
     dev = store.device
     staged = self._staged(dev)
+    device_side = self.plane.device_side
     shard = _ShardView(store, a, b)
     has_state = k == 0 and store.num_state_elements > 0
     ns = store.num_state_elements
@@ -552,8 +607,9 @@ class ParameterServerStrategy(Strategy):
     active = self.num_workers
     inflight: Deque[Dict] = collections.deque()
     free_slots = [1, 0]
-    logging.info("parameter server %d/%d serving shard [%d, %d) for %d workers (%s%s)",
-                 k, self.num_ps, a, b, active, self.comm.backend,
+    open_push: Dict[int, Dict] = {}          # `pieces` protocol: worker rank -> push being received
+    logging.info("parameter server %d/%d serving shard [%d, %d) for %d workers (%s, protocol %s%s)",
+                 k, self.num_ps, a, b, active, self.plane.describe(), self.protocol,
                  ", host-staged" if staged else "")
     t0 = time.time()
 
@@ -561,16 +617,35 @@ class ParameterServerStrategy(Strategy):
       return self._buf((tag, slot), count, dtype, None if staged else dev, pinned=staged)
 
     busy = {"recv_wait": 0.0, "apply": 0.0, "pull_stage": 0.0, "pull_send": 0.0, "idle": 0.0}
+    main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+    # device-side plane: [updates applied, updates dropped] counted on the GPU, events that order
+    # the next pull's cast behind the last update and the next update behind the last cast
+    counters = torch.zeros(2, dtype=torch.float32, device=dev) if device_side else None
+    last = {"apply": None, "cast": None}
 
     def finalize(p):
       t1 = time.time()
-      for w in p["works"]:
-        w.wait()
+      if device_side:
+        # stream-ordered: the update waits for the receives on the device, the host moves on
+        ev = torch.cuda.Event()
+        ev.record(self.plane.stream(self.PUSH))
+        main.wait_event(ev)
+        if last["cast"] is not None:
+          main.wait_event(last["cast"])        # a pull in flight still reads the old parameters
+      else:
+        for w in p["works"]:
+          w.wait()
       t2 = time.time()
       busy["recv_wait"] += t2 - t1
-      self._finalize(p, shard, opt, n, ns, has_state, staged, dev)
+      self._finalize(p, shard, opt, n, ns, has_state, staged, dev, counters)
+      if device_side:
+        last["apply"] = torch.cuda.Event()
+        last["apply"].record(main)
+        # the worker's next pieces land in the same buffer: not before this update has read it
+        self.plane.order_after(self.PUSH, last["apply"])
       busy["apply"] += time.time() - t2
-      free_slots.append(p["slot"])
+      if p.get("slot") is not None:
+        free_slots.append(p["slot"])
 
     while active > 0 or inflight:
       if inflight and (active == 0 or not self._request_waiting(k, head)):
@@ -593,6 +668,30 @@ class ParameterServerStrategy(Strategy):
             finalize(p)
         dtype = torch.bfloat16 if (len(parts) > 2 and parts[2] == "bf16") else torch.float32
         t1 = time.time()
+        sends = []
+        if device_side:
+          # cast and send on the pull stream, behind the last update; the host does not wait
+          ps = self.plane.stream(self.PULL)
+          if last["apply"] is not None:
+            ps.wait_event(last["apply"])
+          with torch.cuda.stream(ps):
+            out = store.params[a:b]
+            if n and dtype != torch.float32:
+              half = self._buf("serve_half", n, dtype, dev)
+              half[:n].copy_(out)
+              out = half[:n]
+            st_out = None
+            if has_state:
+              st_out = self._buf("serve_state_dev", ns, torch.float32, dev)
+              st_out[:ns].copy_(store.state)
+          last["cast"] = torch.cuda.Event()
+          last["cast"].record(ps)
+          if n:
+            self._isend(out, src, self.PULL)
+          if has_state:
+            self._isend(st_out[:ns], src, self.PULL)
+          busy["pull_stage"] += time.time() - t1
+          continue
         if n:
           out = store.params[a:b]
           if dtype != torch.float32:
@@ -604,8 +703,6 @@ class ParameterServerStrategy(Strategy):
             host[:n].copy_(out)                # synchronous device-to-host copy
             out = host[:n]
           sends = self._isend(out, src, self.PULL)
-        else:
-          sends = []
         t2 = time.time()
         busy["pull_stage"] += t2 - t1
         if has_state:
@@ -634,7 +731,7 @@ class ParameterServerStrategy(Strategy):
         if has_state:
           state = land("ps_state", slot, ns, torch.float32)
           works += self._irecv(state[:ns], src, self.PUSH)
-        trailer = torch.zeros(1, dtype=torch.float32, device="cpu" if staged else dev)
+        trailer = torch.zeros(2, dtype=torch.float32, device="cpu" if staged else dev)
         works += self._irecv(trailer, src, self.PUSH)
         p = dict(src=src, slot=slot, lr=lr, divisor=divisor, grads=grads, state=state,
                  trailer=trailer, works=works)
@@ -642,32 +739,90 @@ class ParameterServerStrategy(Strategy):
           inflight.append(p)
         else:
           finalize(p)
+      elif op == "piece":
+        # a bucket that is ready at the sender: the receive is posted at once (it never waits),
+        # into the landing buffer that belongs to this worker
+        dtype = torch.bfloat16 if parts[2] == "bf16" else torch.float32
+        lo, hi = (int(v) for v in parts[3].split("-"))
+        if not 0 <= lo < hi <= n:
+          raise RuntimeError("parameter server: bad piece in %r" % msg)
+        p = open_push.get(src)
+        if p is None:
+          p = open_push[src] = dict(src=src, slot=None, grads=land("ps_land", ("w", src), n, dtype),
+                                    works=[], covered=0)
+        if p["grads"].dtype != dtype:
+          raise RuntimeError("parameter server: a push changed its format mid-way: %r" % msg)
+        p["works"] += self._irecv(p["grads"][lo:hi], src, self.PUSH)
+        p["covered"] += hi - lo
+      elif op == "commit":
+        p = open_push.pop(src, None)
+        if p is None:                          # a shard without elements, or an empty push
+          p = dict(src=src, slot=None, grads=land("ps_land", ("w", src), n, torch.float32),
+                   works=[], covered=0)
+        if p["covered"] != n:
+          raise RuntimeError("parameter server: push of worker %d covers %d of %d elements"
+                             % (src, p["covered"], n))
+        p["lr"], p["divisor"] = float(parts[2]), float(parts[3])
+        p["state"] = None
+        if has_state:
+          p["state"] = land("ps_state", ("w", src), ns, torch.float32)
+          p["works"] += self._irecv(p["state"][:ns], src, self.PUSH)
+        p["trailer"] = self._buf(("ps_trailer", src), 2, torch.float32,
+                                 "cpu" if (staged or dev.type != "cuda") else dev)
+        p["works"] += self._irecv(p["trailer"], src, self.PUSH)
+        finalize(p)
       elif op == "done":
         active -= 1
       else:
         raise RuntimeError("parameter server: bad request %r" % msg)
+    if open_push:
+      raise RuntimeError("parameter server: workers %s finished with an open push" % sorted(open_push))
     if store.device.type == "cuda":
       torch.cuda.synchronize(store.device)
+    if counters is not None:
+      applied, dropped = (int(v) for v in counters.tolist())
+      self.updates_applied += applied
+      self.updates_dropped += dropped
+      self.plane.check()
     logging.info("parameter server %d: %d updates applied, %d dropped in %.1f s; all workers done "
                  "(seconds: %s)", k, self.updates_applied, self.updates_dropped, time.time() - t0,
                  ", ".join("%s %.2f" % kv for kv in busy.items()))
     return self.updates_applied
 
-  def _finalize(self, p, shard, opt, n, ns, has_state, staged, dev):
-    """Applies one completely received push (or drops it when its trailer says so)."""
+  def _finalize(self, p, shard, opt, n, ns, has_state, staged, dev, counters=None):
+    """Applies one completely received push (or drops it when its trailer `[skip, factor]` says
+    so).  A trailer in device memory is never read by the host: the fused optimizer takes it as
+    its skip flag / gradient factor, the moving statistics are selected on the device and the
+    outcome is counted there."""
     store = shard.store
-    if p["trailer"][0].item() != 0:
+    tr = p["trailer"]
+    momentum = getattr(opt, "momentum", 0.0)
+
+    def widened(g):
+      if g.device != dev:
+        tmp = self._buf("ps_dev", n, g.dtype, dev)
+        tmp[:n].copy_(g[:n], non_blocking=True)
+        g = tmp
+      if g.dtype != torch.float32:
+        wide = self._buf("ps_f32", n, torch.float32, dev)
+        wide[:n].copy_(g[:n])
+        g = wide
+      return g[:n]
+
+    if tr.device.type == "cuda":
       if n:
-        g = p["grads"]
-        if g.device != dev:
-          tmp = self._buf("ps_dev", n, g.dtype, dev)
-          tmp[:n].copy_(g[:n], non_blocking=True)
-          g = tmp
-        if g.dtype != torch.float32:
-          wide = self._buf("ps_f32", n, torch.float32, dev)
-          wide[:n].copy_(g[:n])
-          g = wide
-        shard.apply_sgd(g[:n], p["lr"], getattr(opt, "momentum", 0.0), p["divisor"])
+        shard.apply_sgd(widened(p["grads"]), p["lr"], momentum, p["divisor"], skip=tr)
+      applied = (tr[0] == 0)
+      if has_state:
+        store.state.copy_(torch.where(applied, p["state"][:ns], store.state))
+      if counters is not None:
+        counters[0] += applied
+        counters[1] += ~applied
+      return
+    skip, factor = float(tr[0]), float(tr[1])
+    if skip == 0:
+      if n:
+        shard.apply_sgd(widened(p["grads"]), p["lr"], momentum, p["divisor"] / factor)
       if has_state:
         store.state.copy_(p["state"][:ns], non_blocking=True)
       if staged:
@@ -687,10 +842,12 @@ class _ShardView:
     self.store = store
     self.a, self.b = a, b
 
-  def apply_sgd(self, grads: torch.Tensor, lr: float, momentum: float, divisor: float):
+  def apply_sgd(self, grads: torch.Tensor, lr: float, momentum: float, divisor: float,
+                skip: Optional[torch.Tensor] = None):
+    """`skip`: two device floats [skip flag, gradient factor] read by the kernel itself."""
     from ..ops import fused  # pylint: disable=import-outside-toplevel
     st = self.store
     a, b = self.a, self.b
     fused.sgd_momentum_l2(st.params[a:b], grads, st.slot("momentum")[a:b],
-                          st.l2_vector()[a:b], lr, momentum, 1.0 / divisor)
+                          st.l2_vector()[a:b], lr, momentum, 1.0 / divisor, skip)
     st.version += 1

@@ -231,7 +231,7 @@ def get_distribution_strategy(distribution_strategy="default", num_gpus=0, num_w
   if ds == "parameter_server":
     from .parameter_server import ParameterServerStrategy  # pylint: disable=import-outside-toplevel
     task = resolve_task(gpus_per_task=1)
-    return ParameterServerStrategy(task, use_gpu)
+    return ParameterServerStrategy(task, use_gpu, comm_kind=comm_kind)
 
   raise ValueError("Unrecognized Distribution Strategy: %r" % distribution_strategy)
 

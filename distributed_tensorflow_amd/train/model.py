@@ -234,19 +234,34 @@ class Model:
       half = self.dtype in ("bf16", "fp16")
       st.pull(self.store, half=half)
       ex.params_updated()
-      scale = self._loss_scale()
-      st.begin_push(self.store, self._bucket_list(), self.optimizer.current_lr(), scale, half)
+      ls = self._loss_scale_optimizer()
+      # dynamic loss scaling on the native engine: finiteness pass, scale state machine and the
+      # verdict stay on the GPU; the verdict travels to the PS as the push's trailer and the
+      # host never synchronises with the step
+      on_device = (ls is not None and ls.dynamic and getattr(ex, "native", False)
+                   and self.store.grads.device.type == "cuda")
+      scale = self._loss_scale(ex) if on_device else self._loss_scale()
+      st.begin_push(self.store, self._bucket_list(), self.optimizer.current_lr(),
+                    1.0 if on_device else scale, half)
       soft = getattr(ex, "native", False) and st.orders_side_lane(ex)
       loss, correct = ex.train_step(images, idx, scale, st.on_bucket_ready, soft_joins=soft) \
           if soft else ex.train_step(images, idx, scale, st.on_bucket_ready)
-      finite = True
-      ls = self._loss_scale_optimizer()
+      finite, trailer = True, None
       if ls is not None and ls.dynamic:
-        # the PS applies a push only when its trailer says so: a non-finite gradient is
-        # dropped there and the scale adapts here, as in the synchronous path
-        finite = bool(torch.isfinite(self.store.grads).all().item())
-        ls.update_scale(finite)
-      st.end_push(finite)
+        if soft and self.store.grads.device.type == "cuda":
+          # the executor skipped its joins: weight gradients may still be in flight on the side
+          # lane, and a check that ran ahead of them would miss their inf / nan
+          side = ex.side_stream()
+          if side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(side)
+        if on_device:
+          trailer = ls.device_verdict(self.store, ex)
+        else:
+          # the PS applies a push only when its trailer says so: a non-finite gradient is
+          # dropped there and the scale adapts here, as in the synchronous path
+          finite = bool(torch.isfinite(self.store.grads).all().item())
+          ls.update_scale(finite)
+      st.end_push(finite, trailer)
       self.optimizer.iterations += 1
       return loss, correct
     red = self._grad_reducer()

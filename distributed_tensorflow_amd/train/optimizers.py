@@ -195,6 +195,24 @@ class LossScaleOptimizer(Optimizer):
     executor._loss_scale = None     # its host-side copy of the scale is stale from here on
     return self.inner.apply_gradients(store, grad_divisor, executor, skip=self._dev_state[3:5])
 
+  def device_verdict(self, store: ParamStore, executor) -> torch.Tensor:
+    """Parameter-server worker on the native engine: runs the finiteness pass and the scale
+    state machine on the GPU (ordered behind whatever the current stream has waited for) and
+    returns two device floats `[skip, 1 / scale of these gradients]` - the trailer of the push,
+    which the PS hands to its fused optimizer unread.  A copy: the state itself is overwritten
+    by the next step while the trailer may still be waiting to be sent."""
+    from ..ops import native  # pylint: disable=import-outside-toplevel
+    if self._dev_state is None:
+      dev = store.grads.device
+      self._dev_state = torch.tensor([self._scale, float(self._good_steps), float(self._skipped),
+                                      0.0, 1.0], dtype=torch.float32, device=dev)
+      self._dev_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    native.loss_scale_step(store.grads, self._dev_state, self._dev_flag,
+                           executor.loss_scale_dev, self.growth_steps, self.multiplier)
+    self._bound = executor
+    executor._loss_scale = None     # its host-side copy of the scale is stale from here on
+    return self._dev_state[3:5].clone()
+
   def update_scale(self, finite: bool):
     """Advances the host-side state machine by one step whose gradients were / were not finite
     (used directly by the parameter-server worker, whose update is applied elsewhere)."""

@@ -339,8 +339,13 @@ save(out)
   assert any(abs(r["psum"] - res[0]["psum"]) < 1e-6 * abs(res[0]["psum"]) for r in res[1:])
 
 
-@pytest.mark.parametrize("num_ps,workers,fmt", [(1, 7, "fp32"), (2, 6, "bf16")])
-def test_parameter_server_many_workers_no_deadlock_no_lost_update(tmp_path, num_ps, workers, fmt):
+@pytest.mark.parametrize("num_ps,workers,fmt,protocol", [
+    (1, 7, "fp32", "stream"), (2, 6, "bf16", "stream"),
+    # the RCCL data plane's protocol (a bucket is announced when it is ready to leave, a commit
+    # closes the push, every worker lands in its own buffer), here over gloo
+    (1, 7, "bf16", "pieces"), (2, 6, "fp32", "pieces"), (1, 2, "fp32", "whole")])
+def test_parameter_server_many_workers_no_deadlock_no_lost_update(tmp_path, num_ps, workers, fmt,
+                                                                  protocol):
   """The reference's shape of job (`ps_server/run.sh`: 1 ps + 15 workers) at 8 ranks: every
   worker steps four times with overlapped pulls and bucket-wise pushes (three gradient buckets
   split over the ps shards, fp32 or bfloat16 on the wire, one push of one worker carrying a
@@ -349,7 +354,9 @@ def test_parameter_server_many_workers_no_deadlock_no_lost_update(tmp_path, num_
   ranks' copies."""
   body = COMMON + """
 os.environ["DTF_PS_PUSH_DTYPE"] = %r
+os.environ["DTF_PS_PROTOCOL"] = %r
 strat = S.get_distribution_strategy("parameter_server", num_gpus=0)
+assert strat.protocol == %r
 strat.bucket_bytes = 300000
 from distributed_tensorflow_amd.train.optimizers import LossScaleOptimizer
 m = Model(models.resnet20(), strategy=strat, dtype="fp32", seed=11)
@@ -386,7 +393,7 @@ else:
   out["sums"] = [m.store.params[a:b].double().sum().item() for a, b in strat._shards(m.store)]
   strat.shutdown()
 save(out)
-""" % fmt
+""" % (fmt, protocol, protocol)
   res = _run_ranks(tmp_path, body, num_ps + workers, num_ps=num_ps, timeout=600)
   ps, wk = res[:num_ps], res[num_ps:]
   assert all(r["ps"] for r in ps) and not any(r["ps"] for r in wk)
