@@ -148,7 +148,7 @@ class GraphBuilder:
                              True, l2, fan_in=kernel * kernel * c))
     self.ops.append(Op("conv", name, [x], out, dict(
         kh=kernel, kw=kernel, cin=c, cout=filters, stride=stride,
-        pad=(pt, pb, pl, pr))))
+        pad=(pt, pb, pl, pr), padding=padding, explicit_pad=explicit_pad, l2=l2)))
     self.shapes[out] = (ho, wo, filters)
     return out
 
@@ -200,7 +200,8 @@ class GraphBuilder:
     out = out or (name + ":out")
     self.vars.append(VarSpec(name + "/kernel", (n, units), init, True, l2, fan_in=n))
     self.vars.append(VarSpec(name + "/bias", (units,), "zeros", True, l2))
-    self.ops.append(Op("dense", name, [x], out, dict(in_features=n, out_features=units)))
+    self.ops.append(Op("dense", name, [x], out, dict(in_features=n, out_features=units, l2=l2,
+                                                     init=init)))
     self.shapes[out] = (units,)
     return out
 
