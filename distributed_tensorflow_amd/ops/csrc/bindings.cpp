@@ -308,7 +308,9 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     // grad_scale may change per step (dynamic loss scale): an optional device scalar carries it.
     const float gs = get_or<float>(d, "grad_scale", 1.f);
     auto gsd = ptr<const float>(d, "grad_scale_dev", false);   // multiplies grad_scale
-    return [=](hipStream_t s) { launch_softmax_xent(logits, labels, dl, acc, N, C, ld, gs, gsd, dt, s); };
+    // accum[0] += loss * loss_weight: 1 (the default) accumulates the sum, 1 / N the batch mean
+    const float lw = get_or<float>(d, "loss_weight", 1.f);
+    return [=](hipStream_t s) { launch_softmax_xent(logits, labels, dl, acc, N, C, ld, gs, gsd, lw, dt, s); };
   }
   if (kind == "softmax_probs") {
     auto logits = ptr<const void>(d, "logits"); auto probs = ptr<float>(d, "probs");

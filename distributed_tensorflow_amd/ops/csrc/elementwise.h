@@ -67,7 +67,7 @@ void launch_global_mean_bwd(const void* dy, void* dx, int N, int HW, int C, int 
 // accum[0] += sum of per-row losses, accum[1] += number of rows whose argmax equals the label.
 void launch_softmax_xent(const void* logits, const int32_t* labels, void* dlogits,
                          float* accum, int N, int C, int ld, float grad_scale,
-                         const float* grad_scale_dev, int dt, hipStream_t s);
+                         const float* grad_scale_dev, float loss_weight, int dt, hipStream_t s);
 void launch_softmax_probs(const void* logits, float* probs, int N, int C, int ld, int dt,
                           hipStream_t s);
 void launch_colsum(const void* x, float* out, int N, int C, int ld, int dt, int slices_req,

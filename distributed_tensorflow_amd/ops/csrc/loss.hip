@@ -39,7 +39,7 @@ template <int DT, bool PROBS>
 __global__ __launch_bounds__(TPB) void softmax_xent_kernel(
     const void* __restrict__ logits_v, const int32_t* __restrict__ labels,
     void* __restrict__ dlogits_v, float* __restrict__ probs, float* accum, int N, int C, int ld,
-    float grad_scale, const float* __restrict__ grad_scale_dev) {
+    float grad_scale, const float* __restrict__ grad_scale_dev, float loss_weight) {
   typedef typename Elem<DT>::T T;
   const T* logits = reinterpret_cast<const T*>(logits_v);
   T* dlogits = reinterpret_cast<T*>(dlogits_v);
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(TPB) void softmax_xent_kernel(
   }
   if (threadIdx.x == 0) {
     const float ly = (label >= 0 && label < C) ? to_f<DT>(lr[label]) : 0.f;
-    atomicAdd(accum + 0, logf(sum) + bmax - ly);
+    atomicAdd(accum + 0, (logf(sum) + bmax - ly) * loss_weight);   // 1: loss sum, 1 / N: the mean
     if (arg == label) atomicAdd(accum + 1, 1.f);
   }
 }
@@ -120,12 +120,12 @@ __global__ void colsum_kernel(const void* __restrict__ xv, float* __restrict__ o
 
 void launch_softmax_xent(const void* logits, const int32_t* labels, void* dlogits,
                          float* accum, int N, int C, int ld, float grad_scale,
-                         const float* grad_scale_dev, int dt, hipStream_t s) {
+                         const float* grad_scale_dev, float loss_weight, int dt, hipStream_t s) {
   if (C > TPB * MAXV || ld > TPB * MAXV || ld < C)
     throw std::invalid_argument("softmax_xent: at most 4096 classes, ld >= C");
   DTF_DT_SWITCH(dt, hipLaunchKernelGGL((softmax_xent_kernel<DT, false>), dim3(N), dim3(TPB), 0, s,
                                        logits, labels, dlogits, (float*)nullptr, accum, N, C, ld,
-                                       grad_scale, grad_scale_dev));
+                                       grad_scale, grad_scale_dev, loss_weight));
 }
 
 void launch_softmax_probs(const void* logits, float* probs, int N, int C, int ld, int dt,
@@ -133,7 +133,7 @@ void launch_softmax_probs(const void* logits, float* probs, int N, int C, int ld
   if (C > TPB * MAXV || ld < C) throw std::invalid_argument("softmax_probs: at most 4096 classes");
   DTF_DT_SWITCH(dt, hipLaunchKernelGGL((softmax_xent_kernel<DT, true>), dim3(N), dim3(TPB), 0, s,
                                        logits, (const int32_t*)nullptr, (void*)nullptr, probs,
-                                       (float*)nullptr, N, C, ld, 1.f, (const float*)nullptr));
+                                       (float*)nullptr, N, C, ld, 1.f, (const float*)nullptr, 1.f));
 }
 
 void launch_colsum(const void* x, float* out, int N, int C, int ld, int dt, int slices_req,

@@ -139,7 +139,7 @@ class GradientReducer:
         try:
           self._native = rccl.get_native_comm(self.comm) or False
         except Exception as e:  # pylint: disable=broad-except
-          if (self.comm_kind or os.environ.get("DTF_COMM", "")).lower() == "native":
+          if "native" in ((self.comm_kind or "").lower(), os.environ.get("DTF_COMM", "").lower()):
             raise
           from ..utils import logging  # pylint: disable=import-outside-toplevel
           logging.warning("native RCCL communicator unavailable (%s): gradient collectives go "
@@ -194,8 +194,9 @@ class GradientReducer:
         nat.broadcast(g, 0)
         self.collectives_launched += 2
       else:
+        before = nat.collectives
         nat.all_reduce(g, {"ring": "direct", "mesh": "mesh"}.get(self.alg, "auto"))
-        self.collectives_launched += 1
+        self.collectives_launched += nat.collectives - before      # direct / mesh: two phases
       return None
     if self.alg == "mesh" and g.numel() % self.n == 0 and self.n > 1:
       self.collectives_launched += 2

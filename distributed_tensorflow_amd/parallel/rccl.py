@@ -181,7 +181,9 @@ def new_native_comm(comm, watchdog: bool = True) -> NativeComm:
 def comm_choice(backend: str, device_type: str, requested: Optional[str] = None) -> str:
   """`native` or `torch` for the gradient collectives of a job: what `--comm` / `DTF_COMM` ask
   for, else the engine's communicator whenever the job runs on RCCL with the extension built."""
-  want = (requested or os.environ.get("DTF_COMM") or "auto").lower()
+  want = (requested or "auto").lower()
+  if want == "auto":                   # the flag left at its default: the environment may decide
+    want = (os.environ.get("DTF_COMM") or "auto").lower()
   if want not in ("auto", "native", "torch"):
     raise ValueError("--comm must be native, torch or auto (got %r)" % want)
   if backend != "nccl" or device_type != "cuda":
