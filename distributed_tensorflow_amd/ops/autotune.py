@@ -79,6 +79,15 @@ def lookup(kind: str, desc: Dict) -> Optional[Dict[str, int]]:
   return _load().get(sig)
 
 
+def _rows_candidates(desc: Dict) -> List[int]:
+  """48..51: the whole-rows kernel of conv_rows.hip for the large 3x3 unit-stride layers (every
+  input pixel fetched once instead of once per tap): 56x56x64 and 28x28x128."""
+  if desc.get("TI") != 3 or desc.get("TJ") != 3 or desc.get("ISH", 1) != 1 or desc.get("OSH", 1) != 1:
+    return []
+  key = (desc.get("Cpix"), desc.get("W"), desc.get("Cout"))
+  return {(64, 56, 64): [48, 50, 52, 53], (128, 28, 128): [49, 51]}.get(key, [])
+
+
 def _fwd_candidates(desc: Dict) -> List[int]:
   cout = desc["Cout"]
   # 40..47: the one-round-trip kernel for small layers (conv_halo.hip); a descriptor it cannot
@@ -97,9 +106,9 @@ def _fwd_candidates(desc: Dict) -> List[int]:
   # 16..: the multi-stage pipeline of conv_pipe.hip (descriptors it cannot serve fall back to
   # the two-stage tile of the same footprint, so listing them is always safe)
   if cout <= 64:
-    return [1, 5, 0, 21, 22, 23, 20, 10, 11, 14, 15, 32, 34] + halo
+    return [1, 5, 0, 21, 22, 23, 20, 10, 11, 14, 15, 32, 34] + halo + _rows_candidates(desc)
   wide = [29, 30, 31] if cout >= 256 else []       # 256 output channels per block
-  return [0, 6, 4, 5, 1, 16, 17, 18, 19, 20, 21, 24, 25, 26, 27, 28] + wide
+  return [0, 6, 4, 5, 1, 16, 17, 18, 19, 20, 21, 24, 25, 26, 27, 28] + wide + _rows_candidates(desc)
 
 
 def _wgrad_candidates(desc: Dict) -> List[Tuple[int, int]]:
@@ -211,10 +220,16 @@ def tune(kind: str, desc: Dict) -> Dict[str, int]:
   return best
 
 
+# predicate (kind, desc) -> bool: entries to measure again although the table has them (a new
+# kernel family joined the candidates of some shapes); set by scripts/autotune_models.py
+RETUNE = None
+
+
 def apply(kind: str, desc: Dict) -> Dict:
   """Returns `desc` with the tuned configuration filled in (tuning it first when enabled)."""
   hit = lookup(kind, desc)
-  if hit is None and enabled():
+  if enabled() and (hit is None or (RETUNE is not None and RETUNE(kind, desc)
+                                    and signature(kind, desc) not in _retuned)):
     hit = tune(kind, desc)
   if hit is not None:
     desc = dict(desc)

@@ -720,6 +720,9 @@ PYBIND11_MODULE(_dtf_native, m) {
       .def("recv", [](dtf::RcclComm& c, uintptr_t p, size_t n, int dt, int peer, uintptr_t s) {
              c.recv(reinterpret_cast<void*>(p), n, dt, peer, reinterpret_cast<hipStream_t>(s)); },
            py::arg("ptr"), py::arg("count"), py::arg("dt"), py::arg("peer"), py::arg("stream") = 0);
+  m.def("conv_rows_serves", [](const py::dict& d) {
+    return conv_rows_serves(conv_from_dict(d), get_or<int>(d, "cfg", 0));
+  }, "True when the whole-rows 3x3 kernel (conv_rows.hip) runs this convolution descriptor with its cfg");
   m.def("fastdiv_check", [](uint32_t n, uint32_t d) { return fd_div(n, make_fastdiv(d)); });
   m.def("pack_desc_size", []() { return (int)sizeof(PackDesc); });
   m.def("bn_workspace_floats", []() { return bn_workspace_floats(); });

@@ -516,7 +516,8 @@ void validate_conv_params(const ConvParams& p) {
 // cfg 0..15 and 32..39: the kernel of this file; cfg 16..31: the multi-stage pipeline of
 // conv_pipe.hip, which hands descriptors that need the generic gather back to the tile of
 // this file with the same footprint; cfg 40..47: the one-round-trip kernel for small layers of
-// conv_halo.hip (same fallback rule; the only one that runs a BatchNorm prologue).
+// conv_halo.hip (same fallback rule; the only one that runs a BatchNorm prologue); cfg 48..55: the
+// whole-rows kernel for large 3x3 layers of conv_rows.hip (falls back to a pipeline tile).
 void launch_conv_igemm(const ConvParams& p, int cfg, hipStream_t stream) {
   validate_conv_params(p);
   if (cfg >= 40 && cfg < 48) {
@@ -526,6 +527,10 @@ void launch_conv_igemm(const ConvParams& p, int cfg, hipStream_t stream) {
     cfg = halo_fallback_cfg(cfg);
   } else if (p.pro.sums || p.bpro.sums) {
     throw std::invalid_argument("conv: a BatchNorm prologue needs a tile configuration of conv_halo.hip (40..47)");
+  }
+  if (cfg >= 48 && cfg < 56) {
+    if (launch_conv_rows(p, cfg, stream)) return;
+    cfg = rows_fallback_cfg(cfg);
   }
   if (cfg >= 16 && cfg < 32) {
     if (p.dt != DT_F32 && launch_conv_pipe(p, cfg, stream)) return;

@@ -132,4 +132,9 @@ int pipe_fallback_cfg(int cfg);
 // conv_halo.hip: false when the tile cannot serve the descriptor
 bool launch_conv_halo(const ConvParams& p, int cfg, hipStream_t stream);
 int halo_fallback_cfg(int cfg);
+// conv_rows.hip: 3x3 unit-stride layers over whole image rows; false when the tile cannot serve
+// the descriptor
+bool launch_conv_rows(const ConvParams& p, int cfg, hipStream_t stream);
+bool conv_rows_serves(const ConvParams& p, int cfg);
+int rows_fallback_cfg(int cfg);
 void launch_conv_wgrad(const WgradParams& p, int cfg, hipStream_t stream);

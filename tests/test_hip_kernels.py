@@ -193,7 +193,8 @@ def _check_conv_cfg(case, cfg):
     (3, 28, 28, 64, 3, 128, 1, 16), (5, 14, 14, 256, 1, 200, 1, 17), (4, 28, 28, 128, 1, 64, 1, 21),
     (4, 28, 28, 64, 1, 64, 1, 23), (2, 14, 14, 256, 1, 512, 1, 25), (3, 28, 28, 64, 3, 128, 1, 20),
     (3, 17, 17, 16, 3, 16, 1, 8), (3, 17, 17, 16, 3, 32, 1, 9), (4, 16, 16, 32, 3, 64, 1, 10),
-    (4, 16, 16, 32, 3, 64, 1, 11), (3, 17, 17, 16, 3, 16, 1, 12), (3, 17, 17, 32, 3, 32, 1, 13)])
+    (4, 16, 16, 32, 3, 64, 1, 11), (3, 17, 17, 16, 3, 16, 1, 12), (3, 17, 17, 32, 3, 32, 1, 13),
+    (3, 56, 56, 64, 3, 64, 1, 48), (2, 28, 28, 128, 3, 128, 1, 49)])
 def test_conv_fused_bn_statistics(case):
   """The epilogue's per-channel sum / sum of squares equal those of the stored bf16 output,
   followed by the BatchNorm finalize that consumes the replicas."""
@@ -246,7 +247,8 @@ def test_conv_fused_bn_statistics(case):
     # N, H, W, Cin, K, Cout, stride, cfg, with_mask, with_addend
     (3, 20, 20, 64, 3, 72, 1, 0, True, False), (2, 14, 14, 256, 1, 128, 1, 6, True, True),
     (3, 19, 19, 128, 3, 64, 2, 5, True, True), (2, 16, 16, 64, 1, 96, 2, 1, False, False),
-    (3, 17, 17, 16, 3, 32, 1, 3, True, False), (2, 12, 12, 512, 1, 64, 1, 4, True, True)])
+    (3, 17, 17, 16, 3, 32, 1, 3, True, False), (2, 12, 12, 512, 1, 64, 1, 4, True, True),
+    (2, 56, 56, 64, 3, 64, 1, 48, True, True), (2, 28, 28, 128, 3, 128, 1, 51, True, False)])
 def test_dgrad_fused_bn_backward_statistics(case):
   """Data gradient with the backward flavour of the fused statistics: per-channel sum g and
   sum g*y (g = stored bf16 gradient gated by a 1-bit mask) over every parity launch, and the
@@ -1120,3 +1122,24 @@ def test_dgrad_with_batchnorm_backward_prologue(case, cfg):
   _ref_conv(xr, _bf(w).float(), 1, pad).backward(dy.float())
   err = (dx.float() - xr.grad).abs().max().item()
   assert err <= 0.02 * xr.grad.abs().max().item() + 1e-2, err
+
+
+@pytest.mark.parametrize("case,cfg", [
+    ((3, 56, 56, 64, 3, 64, 1), 48), ((2, 56, 56, 64, 3, 128, 1), 50), ((1, 56, 56, 64, 3, 64, 1), 50),
+    ((3, 28, 28, 128, 3, 128, 1), 49), ((2, 28, 28, 128, 3, 256, 1), 51), ((5, 28, 28, 128, 3, 128, 1), 51)])
+def test_conv_whole_rows_kernel(case, cfg):
+  """conv_rows.hip (tile configurations 48..51: the large 3x3 unit-stride layers over whole image
+  rows, every input pixel fetched once into a halo tile): forward, data gradient and accumulating
+  data gradient against the PyTorch fp32 convolution - and the launches really are served by
+  that kernel, not by a fallback tile."""
+  native = _native()
+  N, H, W, Cin, K, Cout, stride = case
+  pad = same_padding(H, K, stride) + same_padding(W, K, stride)
+  g = ConvGeom(N, H, W, Cin, K, K, Cout, stride, pad)
+  probe = torch.zeros(16, device="cuda")
+  fd = g.fwd(probe.data_ptr(), probe.data_ptr(), probe.data_ptr(), cfg=cfg)
+  assert native.ext().conv_rows_serves(fd)
+  for d in g.dgrad(probe.data_ptr(), probe.data_ptr(), probe.data_ptr(), cfg=cfg):
+    assert native.ext().conv_rows_serves(d) == (Cout == Cin)     # its data gradient has Cin outputs
+  assert not native.ext().conv_rows_serves(dict(fd, cfg=cfg ^ 1))  # the other layer's tile
+  _check_conv_cfg(case, cfg)

@@ -72,7 +72,8 @@ def _has_vm_wait(ins, b):
 
 @pytest.mark.parametrize("obj,kernel", [("conv_igemm.o", "conv_igemm_kernel"),
                                         ("conv_wgrad.o", "conv_wgrad_kernel"),
-                                        ("conv_pipe.o", "conv_pipe_kernel")])
+                                        ("conv_pipe.o", "conv_pipe_kernel"),
+                                        ("conv_rows.o", "conv_rows_kernel")])
 def test_every_dma_barrier_waits_for_vector_memory(obj, kernel, tmp_path):
   funcs = _disassemble(os.path.join(BUILD, obj), tmp_path)
   kernels = {n: i for n, i in funcs.items() if kernel in n}
@@ -112,7 +113,8 @@ def test_pipeline_kernels_keep_loads_in_flight(tmp_path):
   assert deep >= 8
 
 
-@pytest.mark.parametrize("obj", ["conv_igemm.o", "conv_pipe.o", "conv_halo.o", "conv_wgrad.o"])
+@pytest.mark.parametrize("obj", ["conv_igemm.o", "conv_pipe.o", "conv_halo.o", "conv_wgrad.o",
+                                 "conv_rows.o"])
 def test_no_convolution_kernel_spills_registers(obj, tmp_path):
   """Every instantiation of the convolution kernels fits its register budget: no scratch memory
   and no spilled vector register in the code object's kernel metadata.  (A fused epilogue that
