@@ -203,7 +203,16 @@ def main() -> int:
   if strat is not None:
     strat.barrier()
     from distributed_tensorflow_amd.parallel import comm
-    comm.shutdown()
+    try:
+      comm.shutdown()
+    finally:
+      # the result is out and every rank has passed the barrier: leave without running the
+      # communicators' destructors (a rank that is slow to tear down RCCL must not turn a
+      # finished measurement into a launcher error)
+      sys.stdout.flush()
+      sys.stderr.flush()
+      if on_gpu and a.gpus > 1:
+        os._exit(0)
   return 0
 
 

@@ -37,7 +37,12 @@ FWD_CFGS = {0: (128, 128), 1: (256, 64), 2: (256, 32), 3: (256, 16), 4: (64, 128
             32: (64, 32), 33: (64, 16), 34: (64, 32),
             # one-round-trip kernel for small layers (conv_halo.hip): halo tile + resident weights
             40: (256, 16), 41: (128, 16), 42: (64, 16), 43: (256, 32), 44: (128, 32), 45: (64, 32),
-            46: (64, 32), 47: (64, 64)}
+            46: (64, 32), 47: (64, 64),
+            # whole-rows kernel for large 3x3 unit-stride layers (conv_rows.hip): four output rows
+            # (224 / 112 pixels) x all output channels; ring depth, K-steps per stage and
+            # occupancy vary
+            48: (224, 64), 49: (112, 128), 50: (224, 64), 51: (112, 128), 52: (224, 64),
+            53: (224, 64)}
 # cfg id % 16 -> (BKK rows of dW, BCO output channels); (cfg id % 64) // 16 = log2(wave groups per
 # block); cfg id // 64 = LDS ring depth - 2 (conv_wgrad.hip)
 WGRAD_CFGS = {0: (128, 128), 1: (128, 64), 2: (64, 128), 3: (64, 64), 4: (128, 32),

@@ -157,16 +157,60 @@ class _Group:
     return False
 
 
+def _probe(nc: NativeComm, seconds: float) -> bool:
+  """One small all-reduce on a stream of its own, polled from the host: True when it completed
+  within `seconds` with the right sum."""
+  import time  # pylint: disable=import-outside-toplevel
+  with torch.cuda.device(nc.device):
+    t = torch.ones(1024, device=nc.device, dtype=torch.float32)
+    s = torch.cuda.Stream(nc.device)
+    s.wait_stream(torch.cuda.current_stream(nc.device))
+    nc.all_reduce(t, "oneshot", stream=s.cuda_stream)
+    ev = torch.cuda.Event()
+    ev.record(s)
+    deadline = time.time() + seconds
+    while not ev.query():
+      if time.time() > deadline:
+        return False
+      time.sleep(0.005)
+    return bool((t == float(nc.world_size)).all().item())
+
+
+def _agree(store, key: str, rank: int, world: int, ok: bool) -> bool:
+  """True when every rank reports `ok` - through the rendezvous store, which needs no GPU."""
+  store.set("%s/%d" % (key, rank), b"1" if ok else b"0")
+  return all(bytes(store.get("%s/%d" % (key, r))) == b"1" for r in range(world))
+
+
 def get_native_comm(comm) -> Optional[NativeComm]:
   """The process-wide native communicator over the ranks of `comm` (a `parallel.comm.Communicator`),
-  created on first use; None when the job runs on the CPU."""
+  created on first use; None when the job runs on the CPU.
+
+  A communicator of several ranks is proven before it carries gradients: a small all-reduce must
+  complete with the right sum within `DTF_COMM_PROBE_S` seconds (default 60) on EVERY rank - the
+  verdicts are compared through the rendezvous store.  If any rank fails, all of them abort
+  their communicator and get None: the job continues on `torch.distributed` instead of hanging
+  in its first step (`DTF_COMM=native` turns the fallback into an error)."""
   global _NATIVE
   if _NATIVE is None:
     if comm.device.type != "cuda":
       return None
     store = comm.store() if (comm.world_size > 1 or comm.rehearse) else None
-    _NATIVE = NativeComm(comm.rank, comm.world_size, store if comm.world_size > 1 else None,
-                         comm.device)
+    nc = NativeComm(comm.rank, comm.world_size, store if comm.world_size > 1 else None,
+                    comm.device)
+    if comm.world_size > 1:
+      seconds = float(os.environ.get("DTF_COMM_PROBE_S", "60"))
+      ok = _probe(nc, seconds) if seconds > 0 else True
+      if not _agree(store, "dtf/rccl_probe/%d" % _SEQ, comm.rank, comm.world_size, ok):
+        logging.warning("native RCCL communicator failed its start-up all-reduce on %s: aborted",
+                        "this rank" if not ok else "another rank")
+        nc.close()
+        nc._c.abort()  # pylint: disable=protected-access
+        _NATIVE = False
+        raise RuntimeError("the native RCCL communicator did not pass its start-up probe")
+    _NATIVE = nc
+  if _NATIVE is False:
+    raise RuntimeError("the native RCCL communicator did not pass its start-up probe")
   return _NATIVE
 
 

@@ -571,3 +571,24 @@ else:
   res = _run_ranks(tmp_path, body, 2, num_ps=1)
   assert res[0]["updates"] == 1
   assert res[1]["ok_half"] and res[1]["ok_full"]
+
+
+def test_native_communicator_probe_verdicts_are_agreed_through_the_store():
+  """Every rank must see the same verdict on the start-up all-reduce of the native
+  communicator, or some would train on it while others fall back."""
+  from distributed_tensorflow_amd.parallel import rccl
+
+  class Store(dict):
+    def set(self, k, v):
+      self[k] = v
+
+    def get(self, k):
+      return self[k]
+
+  st = Store()
+  for r in (1, 2):
+    st.set("probe/%d" % r, b"1")
+  assert rccl._agree(st, "probe", 0, 3, True)
+  assert not rccl._agree(st, "probe", 0, 3, False)       # this rank failed
+  st.set("probe/2", b"0")
+  assert not rccl._agree(st, "probe", 0, 3, True)        # another rank failed

@@ -34,6 +34,8 @@ def test_native_communicator_reports_health_and_runs_the_mesh_schedule():
   torch.cuda.synchronize()
   assert torch.equal(t.cpu(), torch.arange(1024, dtype=torch.float32))
   c.check()
+  from distributed_tensorflow_amd.parallel import rccl
+  assert rccl._probe(c, 20.0)                  # the start-up all-reduce of a multi-rank job
   c.close()
 
 
