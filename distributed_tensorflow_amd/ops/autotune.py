@@ -155,6 +155,11 @@ def _wgrad_candidates(desc: Dict) -> List[Tuple[int, int]]:
       for lg, g in ((1, 2), (2, 4)):
         if s >= g and not (c == 8 and g == 4) and (c + 16 * lg, -(-s // g)) not in out:
           out.extend(with_depths(c + 16 * lg, -(-s // g)))
+  # 192: the whole-gradient-per-block kernel of conv_wgrad_rows.hip (56x56x64 3x3, unit stride);
+  # the split count is kept for the fallback tile
+  if (desc.get("TI"), desc.get("TJ"), desc.get("Cpix"), desc.get("W"), cout) == (3, 3, 64, 56, 64) \
+      and desc.get("ISH", 1) == 1 and desc.get("batch") is None and out:
+    out.append((192, out[0][1]))
   return out
 
 

@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 ARCH = "gfx950"
-SOURCES = ["conv_igemm.hip", "conv_pipe.hip", "conv_halo.hip", "conv_rows.hip", "conv_wgrad.hip", "bn.hip", "pool.hip", "loss.hip", "optim.hip", "dense.hip",
+SOURCES = ["conv_igemm.hip", "conv_pipe.hip", "conv_halo.hip", "conv_rows.hip", "conv_wgrad_rows.hip", "conv_wgrad.hip", "bn.hip", "pool.hip", "loss.hip", "optim.hip", "dense.hip",
            "rccl_comm.cpp", "bindings.cpp"]
 HEADERS = ["common.h", "conv_params.h", "conv_epilogue.h", "elementwise.h", "rccl_comm.h"]
 

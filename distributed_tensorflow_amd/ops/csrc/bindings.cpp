@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <functional>
 #include <stdexcept>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -158,7 +159,21 @@ WgradParams wgrad_from_dict(const py::dict& d) {
   return p;
 }
 
-Launch make_op(const std::string& kind, const py::dict& d) {
+// Workspace of a whole-rows weight gradient (conv_wgrad_rows.hip).  An op recorded in a plan owns
+// one for the plan's lifetime (ops of different plans and lanes may run at the same time; 75 MB
+// each is small change in 288 GB); immediate launches share one, they run in stream order.
+std::shared_ptr<float> wgrad_rows_workspace(bool planned) {
+  auto alloc = [] {
+    float* p = nullptr;
+    HIP_CHECK(hipMalloc(&p, wgrad_rows_workspace_floats() * sizeof(float)));
+    return std::shared_ptr<float>(p, [](float* q) { (void)hipFree(q); });
+  };
+  if (planned) return alloc();
+  static std::shared_ptr<float> shared = alloc();
+  return shared;
+}
+
+Launch make_op(const std::string& kind, const py::dict& d, bool planned = false) {
   // element type of the activation tensors of the op: 0 bf16 (default), 1 fp16, 2 fp32
   const int dt = get_or<int>(d, "dt", DT_BF16);
   if (kind == "conv") {
@@ -167,8 +182,13 @@ Launch make_op(const std::string& kind, const py::dict& d) {
     return [p, cfg](hipStream_t s) { launch_conv_igemm(p, cfg, s); };
   }
   if (kind == "wgrad") {
-    const WgradParams p = wgrad_from_dict(d);
+    WgradParams p = wgrad_from_dict(d);
     const int cfg = get_or<int>(d, "cfg", 0);
+    if (wgrad_rows_serves(p, cfg) && !get_or<int>(d, "atomic_flush", 0)) {
+      std::shared_ptr<float> ws = wgrad_rows_workspace(planned);
+      p.ws = ws.get();
+      return [p, cfg, ws](hipStream_t s) { launch_conv_wgrad(p, cfg, s); };
+    }
     return [p, cfg](hipStream_t s) { launch_conv_wgrad(p, cfg, s); };
   }
   if (kind == "bn_fwd_train") {
@@ -535,7 +555,7 @@ class Plan {
     if (kind == "fork") e.type = FORK;
     else if (kind == "join") e.type = JOIN;
     else if (kind == "soft_join") e.type = SOFT_JOIN;
-    else e.launch = make_op(kind, args);
+    else e.launch = make_op(kind, args, true);
     if (e.type != OP) {
       hipEvent_t ev;
       HIP_CHECK(hipEventCreateWithFlags(&ev, event_flags()));
@@ -723,6 +743,9 @@ PYBIND11_MODULE(_dtf_native, m) {
   m.def("conv_rows_serves", [](const py::dict& d) {
     return conv_rows_serves(conv_from_dict(d), get_or<int>(d, "cfg", 0));
   }, "True when the whole-rows 3x3 kernel (conv_rows.hip) runs this convolution descriptor with its cfg");
+  m.def("wgrad_rows_serves", [](const py::dict& d) {
+    return wgrad_rows_serves(wgrad_from_dict(d), get_or<int>(d, "cfg", 0));
+  }, "True when the whole-rows weight-gradient kernel (conv_wgrad_rows.hip) runs this descriptor with its cfg");
   m.def("fastdiv_check", [](uint32_t n, uint32_t d) { return fd_div(n, make_fastdiv(d)); });
   m.def("pack_desc_size", []() { return (int)sizeof(PackDesc); });
   m.def("bn_workspace_floats", []() { return bn_workspace_floats(); });

@@ -122,6 +122,9 @@ struct WgradParams {
   int splits = 1, pix_per_split = 0;
   int debug_plain_store = 0;       // timing experiments only: plain stores instead of atomics
   int rev = 0;                     // 1: pixel splits are handed out back to front (see ConvParams::rev)
+  // whole-rows kernel only: wgrad_rows_workspace_floats() floats the blocks store their partial
+  // gradients to (summed into `dw` by a second launch); null: every block adds to `dw` atomically
+  float* ws = nullptr;
   FastDiv divOW, divOH, divCpad, divTJpad;
 };
 
@@ -138,3 +141,9 @@ bool launch_conv_rows(const ConvParams& p, int cfg, hipStream_t stream);
 bool conv_rows_serves(const ConvParams& p, int cfg);
 int rows_fallback_cfg(int cfg);
 void launch_conv_wgrad(const WgradParams& p, int cfg, hipStream_t stream);
+// conv_wgrad_rows.hip: the whole-gradient-per-block kernel for large 3x3 unit-stride layers; false
+// when it cannot serve the descriptor (the caller falls back to a tile of conv_wgrad.hip)
+constexpr int WGRAD_ROWS_CFG = 192;
+bool launch_conv_wgrad_rows(const WgradParams& p, int cfg, hipStream_t stream);
+bool wgrad_rows_serves(const WgradParams& p, int cfg);
+size_t wgrad_rows_workspace_floats();

@@ -459,8 +459,13 @@ void validate_wgrad_params(const WgradParams& p) {
 
 // cfg = tile id (0..15) + 16 * log2(groups) + 64 * (stages - 2): 1, 2 or 4 wave groups per block
 // (tile 8, whose groups have eight waves, allows 1 or 2); LDS ring of 2, 3 or 4 stages.
+// cfg 192: the whole-rows kernel of conv_wgrad_rows.hip.
 void launch_conv_wgrad(const WgradParams& p, int cfg, hipStream_t stream) {
   validate_wgrad_params(p);
+  if (cfg == WGRAD_ROWS_CFG) {
+    if (launch_conv_wgrad_rows(p, cfg, stream)) return;
+    cfg = 0;                   // a descriptor the whole-rows kernel cannot serve: the 128x128 tile
+  }
   if (cfg < 0 || cfg >= 192 || (cfg % 64) >= 48)
     throw std::invalid_argument("conv_wgrad: unknown tile config");
   const int stages = 2 + cfg / 64;

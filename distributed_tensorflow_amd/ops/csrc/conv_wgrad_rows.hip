@@ -1,0 +1,262 @@
+// Weight gradient of the large 3x3 unit-stride layers over whole image rows.
+//
+//   dW[tap][ci][co] += sum over pixels p of X[p + tap, ci] * dY[p, co]
+//
+// The general kernel (conv_wgrad.hip) gives every (k-tile, co-tile) of dW its own blocks, so the
+// nine taps of a 3x3 layer fetch the same input pixels nine times and every k-tile fetches dY
+// again: 1.8 KB through L2 per pixel where the tensors hold 256 bytes (56x56x64: 1.4 GB per
+// launch - the layer runs at the rate of the L2, 146 us for 59 GFLOP).  Here a block owns the
+// WHOLE gradient of the layer (64 x 576 fp32 = 144 accumulator registers per lane) and walks over
+// tiles of TR output rows: the halo tile [(TR + 2) rows][W + 2 pixels][64 channels] of X and the
+// [TR * W pixels][64] tile of dY are fetched once by direct-to-LDS loads, all nine taps are
+// multiplied out of LDS, and the accumulators leave the registers once, at the end of the
+// block's tile range.  512 blocks adding 147 KB each with fp32 atomics take 44 us (atomics of
+// different XCDs meet at the memory side, about 13 cache-line operations per clock whatever the
+// address pattern - more than the multiplication itself), so the blocks store their partial
+// gradients to a workspace with plain stores and a second launch sums them: 16 groups of
+// partials per 4 KB slice, the group sums added to the HWIO gradient with 2.4 MB of atomics.
+//
+// Both MFMA operands need the reduction index (the pixel) contiguous per lane while both tensors
+// are pixel-major: fragments are read with ds_read_b64_tr_b16 (conv_wgrad.hip).  Halo rows are
+// 64 pixels apart in LDS, so a tap's row shift is an immediate offset of the read and only its
+// column shift (0, 1, 2 pixels) needs address arithmetic; the 32-byte channel chunks of a pixel
+// are XOR-swizzled with bits 1 and 3 of the pixel index, which keeps the 8 pixels one 32-lane
+// half reads (p .. p + 3, p + 8 .. p + 11) in 8 distinct bank groups for every shift.
+// Wave w owns input channels 16 w .. 16 w + 15 of all nine taps and all output channels.
+#include <stdexcept>
+
+#include "common.h"
+#include "conv_params.h"
+
+namespace {
+
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page_wr[4] = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((address_space(3))) short4v lds_short4;
+typedef __attribute__((ext_vector_type(8))) short short8v;
+
+// swizzle of the 32-byte chunk index inside a 128-byte row (pixel) of 64 16-bit channels
+__device__ __forceinline__ int swz64(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+
+__device__ __forceinline__ bf16x8 tr_pair(const uint8_t* a0, const uint8_t* a1) {
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)a0);
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)a1);
+  const short8v r = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma32(const bf16x8 a, const bf16x8 b, const f32x4 c) {
+  if constexpr (DT == DT_F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+constexpr int WR_C = 64, WR_COUT = 64, WR_PITCH = 64;
+
+template <int DT, int W, int TR>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(const WgradParams p, int tiles_per_block,
+                                                                 int ntiles) {
+  constexpr int C = WR_C, COUT = WR_COUT, PITCH = WR_PITCH;
+  constexpr int HROWS = TR + 2;
+  constexpr int HBYTES = HROWS * PITCH * C * 2;
+  constexpr int PIX = TR * W;
+  constexpr int KS = PIX / 32;                       // reduction steps of 32 pixels per tile
+  constexpr int YBYTES = PIX * COUT * 2;
+  constexpr int HROUNDS = HBYTES / 4096;             // DMA rounds: 256 threads x 16 bytes
+  static_assert(PIX % 32 == 0 && HBYTES % 4096 == 0 && W + 2 <= PITCH, "tile shape");
+  static_assert(2 * (HBYTES + YBYTES) <= 160 * 1024, "two blocks per compute unit");
+  typedef uint16_t T;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  __shared__ __attribute__((aligned(16))) uint8_t smem[HBYTES + YBYTES];
+  uint8_t* halo = smem;
+  uint8_t* ys = smem + HBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T* __restrict__ gx = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ gy = reinterpret_cast<const T*>(p.dy);
+  const T* zero_page = reinterpret_cast<const T*>(g_zero_page_wr);
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment geometry of this lane: 16-lane group g reads pixels 8 g + qq and 8 g + 4 + qq of a
+  // 32-pixel step, four channels (8 bytes) at channel offset 4 pp of the wave's 16
+  const int g = lane >> 4, idx = lane & 15, qq = idx >> 2, pp = idx & 3;
+  // dY tile rows: this thread fills 16-byte slot (tid & 7) of row (tid >> 3) of every step's tile
+  const int yrow = tid >> 3;
+  const int ych = ((((tid & 7) >> 1) ^ swz64(yrow)) << 1) | (tid & 1);      // logical 16-byte chunk
+
+  const int tiles_h = p.H / TR;
+  const int t0 = blockIdx.x * tiles_per_block;
+  const int t1 = min(t0 + tiles_per_block, ntiles);
+  for (int t = t0; t < t1; ++t) {
+    const int tt = p.rev ? ntiles - 1 - t : t;       // the launch plan's sweep direction
+    const int n = tt / tiles_h, r0 = (tt - n * tiles_h) * TR;
+    if (t != t0) {                 // every wave has read the previous tile
+      dma_wait_all();
+      __syncthreads();
+    }
+    // ---- halo tile: 16-byte position u holds chunk ((u & 7) >> 1 ^ swizzle) of halo pixel u >> 3 ----
+#pragma unroll
+    for (int it = 0; it < HROUNDS; ++it) {
+      const int u = (it * 4 + wave) * 64 + lane;
+      const int hp = u >> 3, s16 = u & 7;
+      const int ch16 = ((((s16 >> 1) ^ swz64(hp)) << 1) | (s16 & 1));
+      const int hr = hp / PITCH, hc = hp % PITCH;
+      const int hi = r0 + hr - 1, wi = hc - 1;
+      const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)W;
+      const T* src = ok ? gx + ((size_t)((n * p.H + hi) * W + wi) * C + ch16 * 8) : zero_page;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(halo + (it * 4 + wave) * 1024), 16, 0, 0);
+    }
+    // ---- dY tile: KS step tiles of [32 pixels][64 channels] ----------------------------------------
+    const size_t pix0 = (size_t)(n * p.H + r0) * W;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const T* src = gy + ((pix0 + s * 32 + yrow) * (size_t)p.ldy + ych * 8);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ys + s * 4096 + wave * 1024), 16, 0, 0);
+    }
+    dma_wait_all();
+    __syncthreads();
+
+    // ---- nine taps x KS steps out of LDS ----------------------------------------------------------
+#pragma unroll 1
+    for (int s = 0; s < KS; ++s) {
+      const uint8_t* yt = ys + s * 4096;
+      bf16x8 yf[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        // channels 16 b + 4 pp .. of rows 8 g + qq and 8 g + 4 + qq (layout of conv_wgrad.hip's tiles)
+        const int ra = 8 * g + qq, rb = ra + 4;
+        yf[b] = tr_pair(yt + ra * 128 + (((b ^ swz64(ra)) << 5) | (pp << 3)),
+                        yt + rb * 128 + (((b ^ swz64(rb)) << 5) | (pp << 3)));
+      }
+      const int q0 = s * 32 + 8 * g + qq, q1 = q0 + 4;
+      const int rr0 = q0 / W, rr1 = q1 / W;
+      const int hb0 = rr0 * PITCH + (q0 - rr0 * W), hb1 = rr1 * PITCH + (q1 - rr1 * W);
+#pragma unroll
+      for (int dj = 0; dj < 3; ++dj) {
+        const int h0 = hb0 + dj, h1 = hb1 + dj;
+        const uint8_t* a0 = halo + h0 * 128 + (((wave ^ swz64(h0)) << 5) | (pp << 3));
+        const uint8_t* a1 = halo + h1 * 128 + (((wave ^ swz64(h1)) << 5) | (pp << 3));
+#pragma unroll
+        for (int di = 0; di < 3; ++di) {
+          const bf16x8 xf = tr_pair(a0 + di * (PITCH * 128), a1 + di * (PITCH * 128));
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[di * 3 + dj][b] = mfma32<DT>(xf, yf[b], acc[di * 3 + dj][b]);
+        }
+      }
+    }
+  }
+  if (t0 >= t1) return;
+
+  // ---- the block's gradient leaves the registers once -----------------------------------------------
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t off = (size_t)(a * C + wave * 16 + fq * 4 + r) * COUT;
+      if (p.ws != nullptr) {
+        float* row = p.ws + (size_t)blockIdx.x * (9 * C * COUT) + off;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) row[b * 16 + fr] = acc[a][b][r];
+      } else {
+        float* row = p.dw + off;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (p.debug_plain_store) row[b * 16 + fr] = acc[a][b][r];
+          else atomicAdd(row + b * 16 + fr, acc[a][b][r]);
+        }
+      }
+    }
+}
+
+// dw[i] += sum over partials g, g + GROUPS, ... of ws[part][i] for the block's slice of 1024 floats
+constexpr int RED_GROUPS = 16, RED_SLICE = 1024, WR_MAX_BLOCKS = 512;
+// (gridDim.y groups; one group: the slice has a single owner, which adds in a fixed order without
+// atomics - the deterministic mode)
+__global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(const float* __restrict__ ws, int nparts,
+                                                                int nfloats, float* __restrict__ dw) {
+  const int i = blockIdx.x * RED_SLICE + threadIdx.x * 4;
+  const int G = gridDim.y;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int g = blockIdx.y;
+  for (; g + 3 * G < nparts; g += 4 * G) {      // four loads in flight
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      v[u] = *reinterpret_cast<const f32x4*>(ws + (size_t)(g + u * G) * nfloats + i);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s[0] += v[u][0]; s[1] += v[u][1]; s[2] += v[u][2]; s[3] += v[u][3]; }
+  }
+  for (; g < nparts; g += G) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)g * nfloats + i);
+    s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+  }
+  if (G == 1) {
+    f32x4 d = *reinterpret_cast<const f32x4*>(dw + i);
+    d[0] += s[0]; d[1] += s[1]; d[2] += s[2]; d[3] += s[3];
+    *reinterpret_cast<f32x4*>(dw + i) = d;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(dw + i + e, s[e]);
+  }
+}
+
+template <int W, int TR>
+bool rows_shape_ok(const WgradParams& p) {
+  return p.W == W && p.H % TR == 0;
+}
+
+template <int W, int TR>
+void launch_rows(const WgradParams& p, hipStream_t stream) {
+  const int ntiles = p.N * (p.H / TR);
+  int blocks = WR_MAX_BLOCKS;                // two blocks on each of the 256 compute units
+  if (blocks > ntiles) blocks = ntiles;
+  const int tpb = (ntiles + blocks - 1) / blocks;
+  blocks = (ntiles + tpb - 1) / tpb;
+  if (p.dt == DT_F16)
+    hipLaunchKernelGGL((conv_wgrad_rows_kernel<DT_F16, W, TR>), dim3(blocks), dim3(256), 0, stream, p, tpb, ntiles);
+  else
+    hipLaunchKernelGGL((conv_wgrad_rows_kernel<DT_BF16, W, TR>), dim3(blocks), dim3(256), 0, stream, p, tpb, ntiles);
+  if (p.ws != nullptr) {
+    constexpr int NF = 9 * WR_C * WR_COUT;
+    static_assert(NF % RED_SLICE == 0, "slices");
+    // splits == 1 is how the engine asks for a summation order that does not depend on timing
+    const int groups = p.splits == 1 ? 1 : (blocks < RED_GROUPS ? blocks : RED_GROUPS);
+    hipLaunchKernelGGL(wgrad_rows_reduce_kernel, dim3(NF / RED_SLICE, groups), dim3(256), 0, stream, p.ws,
+                       blocks, NF, p.dw);
+  }
+}
+
+}  // namespace
+
+// 3x3, unit stride, padding 1, 64 -> 64 channels, 16-bit elements, one layer per launch
+bool wgrad_rows_serves(const WgradParams& p, int cfg) {
+  if (cfg != WGRAD_ROWS_CFG) return false;
+  if (p.batch != nullptr || (p.dt != DT_BF16 && p.dt != DT_F16)) return false;
+  if (p.TI != 3 || p.TJ != 3 || p.ISH != 1 || p.ISW != 1 || p.dh0 != -1 || p.dw0 != -1 || p.dhs != 1 ||
+      p.dws != 1 || p.OH != p.H || p.OW != p.W)
+    return false;
+  if (p.Cpix != WR_C || p.Ctap != WR_C || p.Creal != WR_C || p.Cpad != WR_C || p.Cout != WR_COUT ||
+      p.ldy != WR_COUT || p.TJpad != 3 || p.TJreal != 3)
+    return false;
+  if ((int64_t)p.N * p.H * p.W * WR_C >= (1ll << 31)) return false;
+  return rows_shape_ok<56, 4>(p);
+}
+
+size_t wgrad_rows_workspace_floats() { return (size_t)WR_MAX_BLOCKS * 9 * WR_C * WR_COUT; }
+
+bool launch_conv_wgrad_rows(const WgradParams& p, int cfg, hipStream_t stream) {
+  if (!wgrad_rows_serves(p, cfg)) return false;
+  launch_rows<56, 4>(p, stream);
+  return true;
+}

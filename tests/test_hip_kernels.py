@@ -1143,3 +1143,54 @@ def test_conv_whole_rows_kernel(case, cfg):
     assert native.ext().conv_rows_serves(d) == (Cout == Cin)     # its data gradient has Cin outputs
   assert not native.ext().conv_rows_serves(dict(fd, cfg=cfg ^ 1))  # the other layer's tile
   _check_conv_cfg(case, cfg)
+
+
+@pytest.mark.parametrize("N,dtype", [(3, torch.bfloat16), (1, torch.bfloat16), (5, torch.float16)])
+def test_wgrad_whole_rows_kernel(N, dtype):
+  """conv_wgrad_rows.hip (cfg 192: a block owns the whole gradient of a 56x56x64 3x3 layer, the halo
+  tile of X and the tile of dY fetched once per four output rows) against the PyTorch fp32
+  convolution's weight gradient; on top of a gradient that is already there (it accumulates); and a
+  layer it cannot serve falls back to a tile of the general kernel."""
+  native = _native()
+  dev = torch.device("cuda")
+  H = W = 56
+  Cin = Cout = 64
+  gen = torch.Generator(device="cpu").manual_seed(N)
+  pad = same_padding(H, 3, 1) + same_padding(W, 3, 1)
+  g = ConvGeom(N, H, W, Cin, 3, 3, Cout, 1, pad)
+  x = torch.randn(N, H, W, Cin, generator=gen).to(dtype).to(dev)
+  dy = torch.randn(N, H, W, Cout, generator=gen).to(dtype).to(dev)
+  wr = torch.zeros(3, 3, Cin, Cout, device=dev).requires_grad_(True)
+  _ref_conv(x.float(), wr, 1, pad).backward(dy.float())
+  before = torch.randn(3, 3, Cin, Cout, generator=gen).to(dev)
+  dw = before.clone()
+  d = dict(g.wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), cfg=192),
+           dt={torch.bfloat16: 0, torch.float16: 1}[dtype])
+  assert native.ext().wgrad_rows_serves(d)
+  native.run_op("wgrad", d)                # partial gradients to the workspace, summed by a second launch
+  torch.cuda.synchronize()
+  err = (dw - before - wr.grad).abs().max().item()
+  assert err <= 2e-3 * wr.grad.abs().max().item() + 1e-3, err
+  # one split = the deterministic mode: a fixed summation order, bit for bit the same twice
+  once, twice = torch.zeros_like(dw), torch.zeros_like(dw)
+  for out in (once, twice):
+    native.run_op("wgrad", dict(d, dw=out.data_ptr(), splits=1, rev=1))
+  torch.cuda.synchronize()
+  assert torch.equal(once, twice)
+  assert (once - wr.grad).abs().max().item() <= 2e-3 * wr.grad.abs().max().item() + 1e-3
+  native.run_op("wgrad", dict(d, atomic_flush=1))      # every block adds to the gradient itself
+  torch.cuda.synchronize()
+  err = (dw - before - 2 * wr.grad).abs().max().item()
+  assert err <= 4e-3 * wr.grad.abs().max().item() + 2e-3, err
+  # 28x28x128 is not this kernel's: same cfg, served by the general kernel
+  g2 = ConvGeom(2, 28, 28, 128, 3, 3, 128, 1, same_padding(28, 3, 1) + same_padding(28, 3, 1))
+  x2 = _bf(torch.randn(2, 28, 28, 128, generator=gen)).to(dev)
+  dy2 = _bf(torch.randn(2, 28, 28, 128, generator=gen)).to(dev)
+  wr2 = torch.zeros(3, 3, 128, 128, device=dev).requires_grad_(True)
+  _ref_conv(x2.float(), wr2, 1, same_padding(28, 3, 1) + same_padding(28, 3, 1)).backward(dy2.float())
+  dw2 = torch.zeros(3, 3, 128, 128, device=dev)
+  d2 = g2.wgrad(x2.data_ptr(), dy2.data_ptr(), dw2.data_ptr(), cfg=192)
+  assert not native.ext().wgrad_rows_serves(d2)
+  native.run_op("wgrad", d2)
+  torch.cuda.synchronize()
+  assert (dw2 - wr2.grad).abs().max().item() <= 0.01 * wr2.grad.abs().max().item() + 1e-2
