@@ -80,8 +80,11 @@ def lookup(kind: str, desc: Dict) -> Optional[Dict[str, int]]:
 
 
 def _rows_candidates(desc: Dict) -> List[int]:
-  """48..51: the whole-rows kernel of conv_rows.hip for the large 3x3 unit-stride layers (every
+  """48..54: the whole-rows kernels of conv_rows.hip for the large 3x3 unit-stride layers (every
   input pixel fetched once instead of once per tap): 56x56x64 and 28x28x128."""
+  if (desc.get("TI"), desc.get("TJ"), desc.get("Ctap"), desc.get("Cpix"), desc.get("Cout"),
+      desc.get("OW")) == (7, 1, 32, 4, 64, 112):
+    return [54]                  # the merged-tap ImageNet stem over pairs of output rows
   if desc.get("TI") != 3 or desc.get("TJ") != 3 or desc.get("ISH", 1) != 1 or desc.get("OSH", 1) != 1:
     return []
   key = (desc.get("Cpix"), desc.get("W"), desc.get("Cout"))

@@ -42,7 +42,9 @@ FWD_CFGS = {0: (128, 128), 1: (256, 64), 2: (256, 32), 3: (256, 16), 4: (64, 128
             # (224 / 112 pixels) x all output channels; ring depth, K-steps per stage and
             # occupancy vary
             48: (224, 64), 49: (112, 128), 50: (224, 64), 51: (112, 128), 52: (224, 64),
-            53: (224, 64)}
+            53: (224, 64),
+            # the 7x7 stride-2 stem over pairs of output rows, filter bank resident in LDS
+            54: (224, 64)}
 # cfg id % 16 -> (BKK rows of dW, BCO output channels); (cfg id % 64) // 16 = log2(wave groups per
 # block); cfg id // 64 = LDS ring depth - 2 (conv_wgrad.hip)
 WGRAD_CFGS = {0: (128, 128), 1: (128, 64), 2: (64, 128), 3: (64, 64), 4: (128, 32),

@@ -274,6 +274,137 @@ bool launch_rows(const ConvParams& p, hipStream_t stream, bool probe) {
   return true;
 }
 
+// ---- the ImageNet stem: 7x7 stride 2 on a 4-channel image stored with its zero border ---------------
+//
+// In the merged-tap form of the stem (conv_plan.py) a kernel row is ONE K-step: the 8 x 4
+// (column tap, channel) values of output pixel (r, c) are the 64 contiguous bytes at input pixel
+// (2 r + i, 2 c).  Neighbouring output pixels share 48 of those 64 bytes and the seven kernel rows
+// share input rows, so the generic gather moves 448 bytes through the vector memory path per
+// output pixel for 16 bytes of new input (1.4 GB per launch at batch 256: the layer ran at the
+// rate of the L2, 243 us where its 490 MB of HBM traffic take 100).  Here a block keeps the whole
+// filter bank in LDS (7 K-steps x [64 channels][32] = 28 KB, fetched once) and walks over tiles
+// of two output rows: the nine input rows of a tile are fetched once (18 KB), a lane's operand of
+// K-step i is the 16 bytes at  row (2 r + i), byte 16 (c + fq)  - consecutive lanes read
+// consecutive 16-byte slots, K-step and row are immediate offsets - and the tile is multiplied
+// without a barrier.  The next tile's rows are requested before the epilogue of this one.
+constexpr int STEM_OW = 112, STEM_BN = 64, STEM_PITCH = 2048, STEM_HROUNDS = 5, STEM_KS = 7;
+
+template <int DT, int EPI>
+__global__ __launch_bounds__(256, 3)
+void conv_stem_rows_kernel(const ConvParams p, int tiles_per_block, int ntiles) {
+  constexpr int MR = 7, NR = 2, WN = 32;
+  constexpr int HBYTES = STEM_HROUNDS * 4096, SBYTES = STEM_BN * 64;
+  __shared__ __attribute__((aligned(16))) uint8_t smem[HBYTES + STEM_KS * SBYTES];
+  uint8_t* const halo = smem;
+  uint8_t* const wts = smem + HBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int t0 = blockIdx.x * tiles_per_block;
+  const int t1 = min(t0 + tiles_per_block, ntiles);
+  if (t0 >= t1) return;
+
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const bf16_t* __restrict__ gin = reinterpret_cast<const bf16_t*>(p.in);
+  const bf16_t* __restrict__ gw = reinterpret_cast<const bf16_t*>(p.wgt);
+  const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_rows_zero_page);
+  const int tiles_per_img = p.OH >> 1;
+  const int row_chunks = (p.W * 4) >> 3;             // 16-byte chunks of a stored input row
+
+  // 16-byte position q of the tile image = chunk (q % 128) of input row 2 r0 + q / 128 (r0: the
+  // tile's first output row)
+  auto issue_halo = [&](int t) {
+    const int tt = p.rev ? ntiles - 1 - t : t;
+    const int n = tt / tiles_per_img, r0 = (tt - n * tiles_per_img) * 2;
+#pragma unroll
+    for (int it = 0; it < STEM_HROUNDS; ++it) {
+      const int q = (it * 4 + wave) * 64 + lane;
+      const int hr = q >> 7, ch = q & 127;
+      const bool ok = hr < 9 && ch < row_chunks;
+      const bf16_t* src = ok ? gin + (((size_t)(n * p.H + 2 * r0 + hr) * p.W) * 4 + ch * 8) : zero_page;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(halo + (it * 4 + wave) * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- the filter bank, once: K-step i = kernel row i, rows = output channels, swizzled chunks ----
+  {
+    const int lrow = tid >> 2;
+    const int kvw = (tid & 3) ^ ((-(lrow / (4 * NR))) & 3);
+    const bf16_t* wsrc = gw + ((size_t)lrow * p.ldw + p.wk0 + kvw * 8);
+#pragma unroll
+    for (int i = 0; i < STEM_KS; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + i * p.wsi), (lptr_t)(wts + i * SBYTES + wave * 1024),
+                                       16, 0, 0);
+  }
+  issue_halo(t0);
+
+  const int fr = lane & 15, fq = lane >> 4;
+  int woff[NR];
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr) {
+    const int row = wn * WN + (fr >> 2) * (4 * NR) + nr * 4 + (fr & 3);
+    woff[nr] = row * 64 + ((fq ^ ((-(row / (4 * NR))) & 3)) << 4);
+  }
+  const int xoff = (2 * wm) * STEM_PITCH + ((fr + fq) << 4);       // + mr * 256 + i * STEM_PITCH
+
+  for (int t = t0; t < t1; ++t) {
+    rows_wait_vmcnt<0>();
+    asm volatile("s_barrier" ::: "memory");            // this tile's rows (and the filters) have landed
+    f32x4 acc[NR][MR];
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr) acc[nr][mr] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < STEM_KS; ++i) {
+      u32x4 wf[NR], xf[MR];
+#pragma unroll
+      for (int nr = 0; nr < NR; ++nr) wf[nr] = *reinterpret_cast<const u32x4*>(wts + i * SBYTES + woff[nr]);
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr)
+        xf[mr] = *reinterpret_cast<const u32x4*>(halo + xoff + mr * 256 + i * STEM_PITCH);
+#pragma unroll
+      for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) acc[nr][mr] = mfma_step<DT>(wf[nr], xf[mr], acc[nr][mr]);
+    }
+    // every wave has read the tile: the next one may overwrite it while this one is stored
+    rows_wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + 1 < t1) issue_halo(t + 1);
+    const int tt = p.rev ? ntiles - 1 - t : t;
+    conv_epi::conv_epilogue<MR, NR, true, EPI, DT>(p, acc, tt * (2 * STEM_OW) + wm * STEM_OW,
+                                                   wn * WN + fq * 4 * NR, tt, lane);
+  }
+}
+
+bool stem_rows_supports(const ConvParams& p) {
+  return p.dt != DT_F32 && !p.scale && !p.bias && !p.addend && !p.stats_y && !p.pro.sums && !p.bpro.sums &&
+         p.TI == 7 && p.TJ == 1 && p.Ctap == 32 && p.Cpix == 4 && p.ISH == 2 && p.ISW == 2 &&
+         p.dh0 == 0 && p.dw0 == 0 && p.dhs == 1 && p.wsi == 32 && p.OW == STEM_OW && p.OH % 2 == 0 &&
+         p.OSH == 1 && p.OSW == 1 && p.OOH == 0 && p.OOW == 0 && p.OHfull == p.OH && p.OWfull == p.OW &&
+         p.M == p.N * p.OH * p.OW && p.Cout == STEM_BN && p.ldc == STEM_BN && p.ldw % 8 == 0 &&
+         p.W % 2 == 0 && p.W * 8 <= STEM_PITCH && p.W >= 2 * (STEM_OW - 1) + 8 &&
+         p.H >= 2 * (p.OH - 1) + 7;
+}
+
+bool launch_stem_rows(const ConvParams& p, hipStream_t stream, bool probe) {
+  if (!stem_rows_supports(p)) return false;
+  if (probe) return true;
+  const int ntiles = p.N * (p.OH / 2);
+  int blocks = 768;                                  // three blocks on each of the 256 compute units
+  if (blocks > ntiles) blocks = ntiles;
+  const int tpb = (ntiles + blocks - 1) / blocks;
+  blocks = (ntiles + tpb - 1) / tpb;
+  if (p.dt == DT_F16)
+    hipLaunchKernelGGL((conv_stem_rows_kernel<DT_F16, EPI_PLAIN>), dim3(blocks), dim3(256), 0, stream, p, tpb, ntiles);
+  else
+    hipLaunchKernelGGL((conv_stem_rows_kernel<DT_BF16, EPI_PLAIN>), dim3(blocks), dim3(256), 0, stream, p, tpb, ntiles);
+  return true;
+}
+
 }  // namespace
 
 // True when the descriptor is a 3x3 unit-stride SAME convolution (or its data gradient) over
@@ -291,6 +422,7 @@ bool conv_rows_supports(const ConvParams& p) {
 
 namespace {
 bool rows_dispatch(const ConvParams& p, int cfg, hipStream_t stream, bool probe) {
+  if (cfg == 54) return launch_stem_rows(p, stream, probe);       // the 7x7 stride-2 stem
   if (!conv_rows_supports(p)) return false;
   switch (cfg) {
     //                           C    W  rows  BN  waves  ring  steps / stage  waves / SIMD
@@ -314,6 +446,5 @@ bool launch_conv_rows(const ConvParams& p, int cfg, hipStream_t stream) {
 bool conv_rows_serves(const ConvParams& p, int cfg) { return rows_dispatch(p, cfg, nullptr, true); }
 
 int rows_fallback_cfg(int cfg) {        // the pipeline tile the tuner would otherwise pick
-  (void)cfg;
-  return 30;
+  return cfg == 54 ? 22 : 30;
 }

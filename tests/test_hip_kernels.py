@@ -1194,3 +1194,48 @@ def test_wgrad_whole_rows_kernel(N, dtype):
   native.run_op("wgrad", d2)
   torch.cuda.synchronize()
   assert (dw2 - wr2.grad).abs().max().item() <= 0.01 * wr2.grad.abs().max().item() + 1e-2
+
+
+@pytest.mark.parametrize("N,dtype", [(3, torch.bfloat16), (2, torch.float16)])
+def test_stem_whole_rows_kernel(N, dtype):
+  """conv_rows.hip cfg 54 (the 7x7 stride-2 ImageNet stem over pairs of output rows, filter bank
+  resident in LDS) against the PyTorch fp32 convolution, with the fused BatchNorm statistics of its
+  output; a stem of another width is handed to the pipeline tile."""
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator().manual_seed(N)
+  H = 224
+  dti = {torch.bfloat16: 0, torch.float16: 1}[dtype]
+  g = ConvGeom(N, H, H, 3, 7, 7, 64, 2, (3, 3, 3, 3), mode="merged", dt=dti)
+  img = torch.randn(N, H, H, 3, generator=gen).to(dev)
+  xin = torch.zeros(g.input_shape, dtype=dtype, device=dev)
+  native.run_op("preprocess_pad", dict(N=N, H=H, W=H, Cin=3, pt=3, pl=3, OH=g.Hs, OW=g.Ws, Cpad=4, dt=dti,
+                                       out=xin.data_ptr(), **{"in": img.data_ptr()}))
+  w = (torch.randn(7, 7, 3, 64, generator=gen) * 0.05).to(dev)
+  pd = dict(g.pack_fwd(), src_off=0, dst_off=0, first_block=0)
+  wf = torch.zeros(round_up(pd["count"], 8), dtype=dtype, device=dev)
+  desc = torch.frombuffer(bytearray(native.pack_desc_bytes([pd])), dtype=torch.uint8).to(dev)
+  native.run_op("pack_weights", dict(params=w.contiguous().data_ptr(), packed=wf.data_ptr(), descs=desc.data_ptr(),
+                                     ndesc=1, nblocks=native.pack_blocks(pd), dt=dti))
+  out = torch.full(g.output_shape, float("nan"), dtype=dtype, device=dev)
+  stats = torch.zeros(32, 2, 64, device=dev)
+  d = g.fwd(xin.data_ptr(), wf.data_ptr(), out.data_ptr(), cfg=54, stats=stats.data_ptr(), stats_replicas=32)
+  assert native.ext().conv_rows_serves(d)
+  native.run_op("conv", d)
+  torch.cuda.synchronize()
+  xr = xin[:, 3:3 + H, 3:3 + H, :3].float()
+  ref = _ref_conv(xr, w.to(dtype).float(), 2, (3, 3, 3, 3))
+  assert torch.isfinite(out.float()).all()
+  assert (out.float() - ref).abs().max().item() <= 0.02 * ref.abs().max().item()
+  got = stats.sum(0)
+  o = out.float().reshape(-1, 64)
+  assert torch.allclose(got[0], o.sum(0), rtol=1e-3, atol=1e-1)
+  assert torch.allclose(got[1], (o * o).sum(0), rtol=1e-3, atol=1e-1)
+  # the same launch with the tensors walked back to front
+  out2 = torch.zeros_like(out)
+  native.run_op("conv", dict(d, out=out2.data_ptr(), rev=1, stats=None))
+  torch.cuda.synchronize()
+  assert torch.equal(out2, out)
+  small = ConvGeom(N, 64, 64, 3, 7, 7, 64, 2, (3, 3, 3, 3), mode="merged", dt=dti)
+  probe = torch.zeros(16, device=dev)
+  assert not native.ext().conv_rows_serves(small.fwd(probe.data_ptr(), probe.data_ptr(), probe.data_ptr(), cfg=54))
