@@ -648,6 +648,11 @@ class HipExecutor:
     """Weight gradients run on the plan's side lane: they depend only on tensors that are
     complete at this point and nothing but the bucket's all-reduce / the optimizer consumes
     them, so they overlap the BatchNorm / data-gradient chain."""
+    skip = os.environ.get("DTF_DEBUG_SKIP_WGRAD")      # timing experiments only: "pw56,pw28,all"
+    if skip:
+      pw = desc["TI"] == 1 and desc["TJ"] == 1
+      if "all" in skip or (pw and ("pw%d" % desc["OH"]) in skip.split(",")):
+        return
     if self.overlap_wgrad:
       # A fork is an event record + a cross-stream wait (about 18 us of host time, and a
       # barrier packet in both queues): the weight gradients of `wgrad_group` consecutive
