@@ -165,7 +165,7 @@ class HipExecutor:
       fused_bn_stats = False
     if fused_bn_stats is None:
       fused_bn_stats = os.environ.get("DTF_BN_FUSED_STATS", "1") != "0"
-    self.fused_bn_stats = fused_bn_stats and self.dt in (0, 1)      # the 16-bit element types
+    self.fused_bn_stats = bool(fused_bn_stats)
     self.overlap_wgrad = os.environ.get("DTF_WGRAD_STREAM", "1") != "0"
     self.wgrad_group = int(os.environ.get("DTF_WGRAD_GROUP", "0"))   # 0: decided while planning
     # several layers' weight gradients in one launch: opt-in, fewer launches did not pay
@@ -336,8 +336,8 @@ class HipExecutor:
                                             torch.uint8, zero=False)
     # replica rows for BatchNorm *backward* statistics accumulated by the data-gradient launch
     # that produces the layer's incoming gradient (zeroed by the same memset as the forward ones)
-    self.fused_bn_bwd_stats = self.fused_bn_stats and \
-        os.environ.get("DTF_BN_FUSED_BWD_STATS", "1") != "0"
+    self.fused_bn_bwd_stats = self.fused_bn_stats and self.dt in (0, 1) and \
+        os.environ.get("DTF_BN_FUSED_BWD_STATS", "1") != "0"      # the 16-bit element types
     self._bn_bwd_stats_off: Dict[str, int] = {}
     if self.fused_bn_bwd_stats:
       for b in bn_ops:

@@ -416,15 +416,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
 
 // Epilogue for the element types without fused extras (fp16, fp32; bf16 takes conv_epilogue):
 // out = acc (+ bias) (+ addend, optionally gated by the 1-bit mask), four channels per store.
+// With `p.stats` it also accumulates the BatchNorm statistics of the stored values (sum and sum of
+// squares per channel into replica row `mt % stats_replicas`), as conv_epilogue does.
 template <int DT, int MR, int NR, bool POINTWISE>
 __device__ __forceinline__ void conv_epilogue_plain(const ConvParams& p, f32x4 (&acc)[NR][MR],
-                                                    const int m_base, const int co0,
+                                                    const int m_base, const int co0, const int mt,
                                                     const int lane) {
   typedef typename Elem<DT>::T T;
   const int fr = lane & 15;
   T* out = reinterpret_cast<T*>(p.out);
   const T* addend = reinterpret_cast<const T*>(p.addend);
   const bool vec_ok = (p.ldc % 4 == 0);
+  const bool do_stats = p.stats != nullptr;
 #pragma unroll
   for (int mr = 0; mr < MR; ++mr) {
     const int m = m_base + mr * 16 + fr;
@@ -482,6 +485,37 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvParams& p, f32x4 (
           }
         }
       }
+    }
+  }
+  // Statistics in a pass of their own over the accumulators, one MFMA tile of four channels at a
+  // time: eight running sums instead of 8 * NR next to the accumulators (the fp32 tiles sit at
+  // their register budget; carrying all sums through the store loop spilled thousands of them).
+  // Forward statistics go with a plain convolution (no addend: host check), so the stored value is
+  // the accumulator plus bias, rounded to the element type.
+  if (do_stats) {
+    float* dst = p.stats + (size_t)(mt % p.stats_replicas) * 2 * p.Cout;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+      const int c0 = co0 + nr * 4;
+      float s8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s8[e] = 0.f;
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr) {
+        if (m_base + mr * 16 + fr < p.M) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = acc[nr][mr][e] + ((p.bias && c0 + e < p.Cout) ? p.bias[c0 + e] : 0.f);
+            if constexpr (DT != DT_F32) x = to_f<DT>(from_f<DT>(x));
+            s8[e] += x;
+            s8[4 + e] += x * x;
+          }
+        }
+      }
+      butterfly16<8, 8, 0>(s8, fr);      // three halvings, then the two halves of the 16 lanes are added
+      const int idx = ((fr & 1) << 2) | (((fr >> 1) & 1) << 1) | ((fr >> 2) & 1);
+      const int q = idx >> 2, c = idx & 3;           // quantity (sum / sum of squares), channel
+      if ((fr >> 3) == 0 && c0 + c < p.Cout) atomicAdd(dst + q * p.Cout + c0 + c, s8[0]);
     }
   }
 }

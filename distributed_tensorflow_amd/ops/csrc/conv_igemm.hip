@@ -384,7 +384,7 @@ void conv_igemm_kernel(const ConvParams p) {
                                                         n0 + wn * WN + fq * 4 * NR, mt, lane);
   else
     conv_epi::conv_epilogue_plain<DT, MR, NR, POINTWISE>(p, acc, m0 + wm * WM,
-                                                         n0 + wn * WN + fq * 4 * NR, lane);
+                                                         n0 + wn * WN + fq * 4 * NR, mt, lane);
 }
 
 template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int STAGES = 2>
@@ -407,9 +407,9 @@ void launch_cfg_epi(const ConvParams& p, hipStream_t stream) {
                        dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
 }
 
-// The fused epilogues (BatchNorm statistics, folded inference BatchNorm) exist for the 16-bit
-// types; fp32 launches take the plain epilogue (bias, addend) and the planner schedules the
-// separate statistics sweep / BatchNorm launch for them.
+// The fused epilogues of conv_epilogue (backward statistics, folded inference BatchNorm) exist for
+// the 16-bit types; fp32 launches take the plain epilogue (bias, addend, forward statistics) and
+// the planner schedules separate launches for the rest.
 template <int DT, int BM, int BN, int WAVES_M, int WAVES_N>
 void launch_cfg16(const ConvParams& p, hipStream_t stream) {
   if (p.scale) launch_cfg_epi<DT, BM, BN, WAVES_M, WAVES_N, EPI_INFER>(p, stream);
@@ -441,8 +441,8 @@ void validate_conv_params(const ConvParams& p) {
   auto fail = [](const std::string& m) { throw std::invalid_argument("conv_igemm: " + m); };
   if (!p.in || !p.wgt || !p.out) fail("null tensor pointer");
   if (p.dt != DT_BF16 && p.dt != DT_F16 && p.dt != DT_F32) fail("unknown element type");
-  if (p.dt == DT_F32 && (p.scale || p.stats || p.relu))
-    fail("fused statistics / folded BatchNorm epilogues exist for the 16-bit element types only");
+  if (p.dt == DT_F32 && (p.scale || p.stats_y || p.relu))
+    fail("backward statistics / folded BatchNorm epilogues exist for the 16-bit element types only");
   if (p.N <= 0 || p.H <= 0 || p.W <= 0 || p.OH <= 0 || p.OW <= 0) fail("bad spatial size");
   // the kernels keep a pixel's base row / column as signed 16-bit halves of one register
   if (p.H > 8192 || p.W > 8192 || p.dh0 < -4096 || p.dh0 > 4096 || p.dw0 < -4096 || p.dw0 > 4096 ||

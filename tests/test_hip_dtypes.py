@@ -93,6 +93,18 @@ def test_conv_fwd_dgrad_wgrad_other_types(case, dt):
   ref = _ref_conv(x.float(), wq, stride, pad)
   err = (out.float()[..., :Cout] - ref).abs().max().item()
   assert err <= tol * ref.abs().max().item() + tol * 1e-1, err
+  if dt == 2 and Cout % 8 == 0:
+    # fp32: the plain epilogue also accumulates the BatchNorm statistics of what it stores
+    stats = torch.zeros(4, 2, Cout, device=dev)
+    out2 = torch.zeros_like(out)
+    native.run_op("conv", g.fwd(x.data_ptr(), wf.data_ptr(), out2.data_ptr(), stats=stats.data_ptr(),
+                                stats_replicas=4))
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
+    o = out.float().reshape(-1, g.ldc)[:, :Cout]
+    got = stats.sum(0)
+    assert torch.allclose(got[0], o.sum(0), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(got[1], (o * o).sum(0), rtol=1e-4, atol=1e-3)
   # data gradient, plain and accumulating
   dy = torch.randn(N, g.OH, g.OW, g.ldc, generator=gen).to(td).to(dev)
   dy[..., Cout:] = 0
