@@ -12,7 +12,9 @@
 
 namespace conv_epi {
 
-constexpr int EPI_PLAIN = 0, EPI_BSTATS = 1, EPI_INFER = 2;
+// EPI_ADD: the plain epilogue for launches with an addend (no statistics): addend loads run one
+// pixel block ahead of the stores
+constexpr int EPI_PLAIN = 0, EPI_BSTATS = 1, EPI_INFER = 2, EPI_ADD = 3;
 
 // Value of lane ^ (1 << T) inside a row of 16 lanes, without a trip through the LDS crossbar
 // where the data-parallel-primitive modifiers can express the exchange: quad permutes for the
@@ -245,20 +247,70 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
   float st[2 * CPL];
 #pragma unroll
   for (int c = 0; c < 2 * CPL; ++c) st[c] = 0.f;
+  auto out_pixel = [&](int m) -> size_t {          // linear pixel index in the output tensor
+    if (POINTWISE) return (size_t)m;
+    const uint32_t t = fd_div((uint32_t)m, p.divOW);
+    const int ow = m - (int)t * p.OW;
+    const uint32_t n = fd_div(t, p.divOH);
+    const int oh = (int)t - (int)n * p.OH;
+    return (size_t)((int)n * p.OHfull + oh * p.OSH + p.OOH) * p.OWfull + (ow * p.OSW + p.OOW);
+  };
+  // The addend (and its mask bits) of pixel block mr + 1 is requested before block mr is stored:
+  // written inside the store loop the loads cannot be hoisted over the stores (an accumulating
+  // data gradient adds to the very tensor it writes) and a wave pays a memory latency per block.
+  constexpr bool AHEAD = EPI == EPI_ADD && CPL >= 8;
+  constexpr int HV = AHEAD ? CPL / 8 : 1;
+  u32x4 apre[HV];
+  uint32_t bpre[HV];
+  auto fetch_addend = [&](int mr) {
+    if constexpr (AHEAD) {
+#pragma unroll
+      for (int h = 0; h < HV; ++h) {
+        apre[h] = u32x4{0u, 0u, 0u, 0u};
+        bpre[h] = 0xffu;
+      }
+      const int m = m_base + mr * 16 + fr;
+      if (p.addend != nullptr && vec_ok && m < p.M) {
+        const size_t opix = out_pixel(m);
+        const E* aptr = reinterpret_cast<const E*>(p.addend) + opix * p.ldc + co0;
+#pragma unroll
+        for (int h = 0; h < HV; ++h)
+          if (co0 + h * 8 + 8 <= p.Cout) apre[h] = *reinterpret_cast<const u32x4*>(aptr + h * 8);
+        if (p.addend_mask && co0 + 8 <= p.Cout) {
+          // the lane's HV mask bytes in one load (co0 is a multiple of CPL = 8 HV channels)
+          const uint8_t* mp = p.addend_mask + opix * (p.ldc >> 3) + (co0 >> 3);
+          uint32_t bits;
+          if constexpr (HV == 4) {
+            bits = co0 + 32 <= p.Cout ? *reinterpret_cast<const uint32_t*>(mp)
+                                      : (uint32_t)mp[0] | (co0 + 16 <= p.Cout ? (uint32_t)mp[1] << 8 : 0u) |
+                                            (co0 + 24 <= p.Cout ? (uint32_t)mp[2] << 16 : 0u);
+          } else if constexpr (HV == 2) {
+            bits = co0 + 16 <= p.Cout ? (uint32_t)*reinterpret_cast<const uint16_t*>(mp) : (uint32_t)mp[0];
+          } else {
+            bits = mp[0];
+          }
+#pragma unroll
+          for (int h = 0; h < HV; ++h) bpre[h] = (bits >> (8 * h)) & 0xffu;
+        }
+      }
+    }
+  };
+  fetch_addend(0);
 #pragma unroll
   for (int mr = 0; mr < MR; ++mr) {
+    u32x4 acur[HV];
+    uint32_t bcur[HV];
+    if constexpr (AHEAD) {
+#pragma unroll
+      for (int h = 0; h < HV; ++h) {
+        acur[h] = apre[h];
+        bcur[h] = bpre[h];
+      }
+      if (mr + 1 < MR) fetch_addend(mr + 1);
+    }
     const int m = m_base + mr * 16 + fr;
     if (m >= p.M) continue;
-    size_t opix;                                   // linear pixel index in the output tensor
-    if (POINTWISE) {
-      opix = (size_t)m;
-    } else {
-      const uint32_t t = fd_div((uint32_t)m, p.divOW);
-      const int ow = m - (int)t * p.OW;
-      const uint32_t n = fd_div(t, p.divOH);
-      const int oh = (int)t - (int)n * p.OH;
-      opix = (size_t)((int)n * p.OHfull + oh * p.OSH + p.OOH) * p.OWfull + (ow * p.OSW + p.OOW);
-    }
+    const size_t opix = out_pixel(m);
     const size_t obase = opix * p.ldc;
     E* optr = reinterpret_cast<E*>(p.out) + obase + co0;
     const E* aptr = p.addend ? reinterpret_cast<const E*>(p.addend) + obase + co0 : nullptr;
@@ -273,9 +325,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
         float v6 = acc[2 * h + 1][mr][2] + bias[h * 8 + 6], v7 = acc[2 * h + 1][mr][3] + bias[h * 8 + 7];
         if (vec_ok && co0 + h * 8 + 8 <= p.Cout) {
           if (aptr) {
-            u32x4 a = *reinterpret_cast<const u32x4*>(aptr + h * 8);
+            u32x4 a;
+            if constexpr (AHEAD) a = acur[h];
+            else a = *reinterpret_cast<const u32x4*>(aptr + h * 8);
             if (mptr) {                            // keep only the elements whose mask bit is set
-              const uint32_t b = mptr[h];
+              const uint32_t b = AHEAD ? bcur[h] : (uint32_t)mptr[h];
               a.x &= ((b & 1u) ? 0xffffu : 0u) | ((b & 2u) ? 0xffff0000u : 0u);
               a.y &= ((b & 4u) ? 0xffffu : 0u) | ((b & 8u) ? 0xffff0000u : 0u);
               a.z &= ((b & 16u) ? 0xffffu : 0u) | ((b & 32u) ? 0xffff0000u : 0u);
@@ -293,7 +347,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
           u32x4 o;
           o.x = pack2<DT>(v0, v1); o.y = pack2<DT>(v2, v3); o.z = pack2<DT>(v4, v5); o.w = pack2<DT>(v6, v7);
           *reinterpret_cast<u32x4*>(optr + h * 8) = o;
-          if (EPI != EPI_INFER && p.stats) {
+          if (EPI != EPI_INFER && EPI != EPI_ADD && p.stats) {
             const uint32_t w[4] = {o.x, o.y, o.z, o.w};
             if constexpr (BSTATS) {                  // sum g, sum g * y  (g = masked output)
               const u32x4 yq = *reinterpret_cast<const u32x4*>(reinterpret_cast<const E*>(p.stats_y) + obase + co0 + h * 8);
@@ -354,7 +408,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
         o.x = pack2<DT>(v0, v1);
         o.y = pack2<DT>(v2, v3);
         *reinterpret_cast<u32x2*>(optr) = o;
-        if (EPI != EPI_INFER && p.stats) {
+        if (EPI != EPI_INFER && EPI != EPI_ADD && p.stats) {
           const uint32_t w[2] = {o.x, o.y};
           if constexpr (BSTATS) {
             const u32x2 yq = *reinterpret_cast<const u32x2*>(reinterpret_cast<const E*>(p.stats_y) + obase + co0);
@@ -394,7 +448,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
       }
     }
   }
-  if (EPI != EPI_INFER && p.stats) {
+  if (EPI != EPI_INFER && EPI != EPI_ADD && p.stats) {
     constexpr int NV = 2 * CPL;
     constexpr int HALVINGS = NV >= 16 ? 4 : 3;     // NV is 8, 16 or 32
     constexpr int LEFT = NV >> HALVINGS;           // totals per lane afterwards

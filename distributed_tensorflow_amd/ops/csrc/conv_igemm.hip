@@ -67,6 +67,7 @@ constexpr int GENERIC = 0, POINTWISE_MODE = 1, TAPLOOP = 2;
 //   EPI_BSTATS  backward flavour of the fused statistics (sum g, sum g*y; see ConvParams)
 //   EPI_INFER   folded BatchNorm for inference: acc * scale + bias (+ addend), optional ReLU
 using conv_epi::EPI_PLAIN;
+using conv_epi::EPI_ADD;
 using conv_epi::EPI_BSTATS;
 using conv_epi::EPI_INFER;
 
@@ -414,6 +415,7 @@ template <int DT, int BM, int BN, int WAVES_M, int WAVES_N>
 void launch_cfg16(const ConvParams& p, hipStream_t stream) {
   if (p.scale) launch_cfg_epi<DT, BM, BN, WAVES_M, WAVES_N, EPI_INFER>(p, stream);
   else if (p.stats_y) launch_cfg_epi<DT, BM, BN, WAVES_M, WAVES_N, EPI_BSTATS>(p, stream);
+  else if (p.addend && !p.stats) launch_cfg_epi<DT, BM, BN, WAVES_M, WAVES_N, EPI_ADD>(p, stream);
   else launch_cfg_epi<DT, BM, BN, WAVES_M, WAVES_N, EPI_PLAIN>(p, stream);
 }
 
@@ -430,6 +432,7 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
 void launch_ring(const ConvParams& p, hipStream_t stream) {
   if (p.dt != DT_BF16 || p.scale) return launch_cfg<BM, BN, WAVES_M, WAVES_N>(p, stream);
   if (p.stats_y) launch_cfg_epi<DT_BF16, BM, BN, WAVES_M, WAVES_N, EPI_BSTATS, STAGES>(p, stream);
+  else if (p.addend && !p.stats) launch_cfg_epi<DT_BF16, BM, BN, WAVES_M, WAVES_N, EPI_ADD, STAGES>(p, stream);
   else launch_cfg_epi<DT_BF16, BM, BN, WAVES_M, WAVES_N, EPI_PLAIN, STAGES>(p, stream);
 }
 

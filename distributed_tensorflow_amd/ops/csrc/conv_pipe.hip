@@ -40,6 +40,7 @@
 
 namespace {
 
+using conv_epi::EPI_ADD;
 using conv_epi::EPI_BSTATS;
 using conv_epi::EPI_INFER;
 using conv_epi::EPI_PLAIN;
@@ -318,6 +319,7 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int STAGES, int DT>
 bool launch_pipe_dt(const ConvParams& p, hipStream_t stream) {
   if (p.scale) return launch_pipe_epi<BM, BN, WAVES_M, WAVES_N, BK, STAGES, EPI_INFER, DT>(p, stream);
   if (p.stats_y) return launch_pipe_epi<BM, BN, WAVES_M, WAVES_N, BK, STAGES, EPI_BSTATS, DT>(p, stream);
+  if (p.addend && !p.stats) return launch_pipe_epi<BM, BN, WAVES_M, WAVES_N, BK, STAGES, EPI_ADD, DT>(p, stream);
   return launch_pipe_epi<BM, BN, WAVES_M, WAVES_N, BK, STAGES, EPI_PLAIN, DT>(p, stream);
 }
 
