@@ -208,10 +208,70 @@ __device__ __forceinline__ void conv_epilogue_bstats(const ConvParams& p, f32x4 
 
 // m_base: first pixel row of this wave's sub-tile (m0 + wm*WM); co0: see above; mt: M-tile
 // index of the block (selects the statistics replica).
+template <bool POINTWISE>
+__device__ __forceinline__ size_t out_pixel_index(const ConvParams& p, int m) {
+  if (POINTWISE) return (size_t)m;
+  const uint32_t t = fd_div((uint32_t)m, p.divOW);
+  const int ow = m - (int)t * p.OW;
+  const uint32_t n = fd_div(t, p.divOH);
+  const int oh = (int)t - (int)n * p.OH;
+  return (size_t)((int)n * p.OHfull + oh * p.OSH + p.OOH) * p.OWfull + (ow * p.OSW + p.OOW);
+}
+
+// Addend pieces and mask bytes of one pixel block of a lane, requested ahead of their use
+// (EPI_ADD): the kernels ask for block 0 before their K loop - the addend does not depend on the
+// product - and the epilogue for block mr + 1 before it stores block mr.
+template <int NR, int EPI>
+struct AddendAhead {
+  static constexpr bool ON = EPI == EPI_ADD && NR >= 2;
+  static constexpr int HV = ON ? NR / 2 : 1;       // 16-byte pieces of a lane's 4 NR channels
+  u32x4 a[HV];
+  uint32_t b[HV];
+};
+
+template <int NR, bool POINTWISE, int EPI, int DT>
+__device__ __forceinline__ void addend_fetch(const ConvParams& p, AddendAhead<NR, EPI>& pre, const int m,
+                                             const int co0) {
+  typedef typename Elem<DT>::T E;
+  constexpr int HV = AddendAhead<NR, EPI>::HV;
+  if constexpr (AddendAhead<NR, EPI>::ON) {
+#pragma unroll
+    for (int h = 0; h < HV; ++h) {
+      pre.a[h] = u32x4{0u, 0u, 0u, 0u};
+      pre.b[h] = 0xffu;
+    }
+    if (p.addend != nullptr && p.ldc % 8 == 0 && m < p.M) {
+      const size_t opix = out_pixel_index<POINTWISE>(p, m);
+      const E* aptr = reinterpret_cast<const E*>(p.addend) + opix * p.ldc + co0;
+#pragma unroll
+      for (int h = 0; h < HV; ++h)
+        if (co0 + h * 8 + 8 <= p.Cout) pre.a[h] = *reinterpret_cast<const u32x4*>(aptr + h * 8);
+      if (p.addend_mask && co0 + 8 <= p.Cout) {
+        // the lane's HV mask bytes in one load (co0 is a multiple of 8 HV channels)
+        const uint8_t* mp = p.addend_mask + opix * (p.ldc >> 3) + (co0 >> 3);
+        uint32_t bits;
+        if constexpr (HV == 4) {
+          bits = co0 + 32 <= p.Cout ? *reinterpret_cast<const uint32_t*>(mp)
+                                    : (uint32_t)mp[0] | (co0 + 16 <= p.Cout ? (uint32_t)mp[1] << 8 : 0u) |
+                                          (co0 + 24 <= p.Cout ? (uint32_t)mp[2] << 16 : 0u);
+        } else if constexpr (HV == 2) {
+          bits = co0 + 16 <= p.Cout ? (uint32_t)*reinterpret_cast<const uint16_t*>(mp) : (uint32_t)mp[0];
+        } else {
+          bits = mp[0];
+        }
+#pragma unroll
+        for (int h = 0; h < HV; ++h) pre.b[h] = (bits >> (8 * h)) & 0xffu;
+      }
+    }
+  }
+}
+
+// `first`: the addend of the lane's pixel block 0, requested by the caller before its K loop
+// (EPI_ADD; null: requested here).
 template <int MR, int NR, bool POINTWISE, int EPI, int DT = DT_BF16>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[NR][MR],
                                               const int m_base, const int co0, const int mt,
-                                              const int lane) {
+                                              const int lane, const AddendAhead<NR, EPI>* first = nullptr) {
   static_assert(DT == DT_BF16 || DT == DT_F16, "the fused epilogue packs two 16-bit elements per word");
   if constexpr (EPI == EPI_BSTATS) {
     conv_epilogue_bstats<MR, NR, POINTWISE, DT>(p, acc, m_base, co0, mt, lane);
@@ -247,55 +307,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
   float st[2 * CPL];
 #pragma unroll
   for (int c = 0; c < 2 * CPL; ++c) st[c] = 0.f;
-  auto out_pixel = [&](int m) -> size_t {          // linear pixel index in the output tensor
-    if (POINTWISE) return (size_t)m;
-    const uint32_t t = fd_div((uint32_t)m, p.divOW);
-    const int ow = m - (int)t * p.OW;
-    const uint32_t n = fd_div(t, p.divOH);
-    const int oh = (int)t - (int)n * p.OH;
-    return (size_t)((int)n * p.OHfull + oh * p.OSH + p.OOH) * p.OWfull + (ow * p.OSW + p.OOW);
-  };
+  auto out_pixel = [&](int m) -> size_t { return out_pixel_index<POINTWISE>(p, m); };
   // The addend (and its mask bits) of pixel block mr + 1 is requested before block mr is stored:
   // written inside the store loop the loads cannot be hoisted over the stores (an accumulating
   // data gradient adds to the very tensor it writes) and a wave pays a memory latency per block.
-  constexpr bool AHEAD = EPI == EPI_ADD && CPL >= 8;
-  constexpr int HV = AHEAD ? CPL / 8 : 1;
-  u32x4 apre[HV];
-  uint32_t bpre[HV];
+  constexpr bool AHEAD = AddendAhead<NR, EPI>::ON;
+  constexpr int HV = AddendAhead<NR, EPI>::HV;
+  AddendAhead<NR, EPI> pre;
   auto fetch_addend = [&](int mr) {
-    if constexpr (AHEAD) {
-#pragma unroll
-      for (int h = 0; h < HV; ++h) {
-        apre[h] = u32x4{0u, 0u, 0u, 0u};
-        bpre[h] = 0xffu;
-      }
-      const int m = m_base + mr * 16 + fr;
-      if (p.addend != nullptr && vec_ok && m < p.M) {
-        const size_t opix = out_pixel(m);
-        const E* aptr = reinterpret_cast<const E*>(p.addend) + opix * p.ldc + co0;
-#pragma unroll
-        for (int h = 0; h < HV; ++h)
-          if (co0 + h * 8 + 8 <= p.Cout) apre[h] = *reinterpret_cast<const u32x4*>(aptr + h * 8);
-        if (p.addend_mask && co0 + 8 <= p.Cout) {
-          // the lane's HV mask bytes in one load (co0 is a multiple of CPL = 8 HV channels)
-          const uint8_t* mp = p.addend_mask + opix * (p.ldc >> 3) + (co0 >> 3);
-          uint32_t bits;
-          if constexpr (HV == 4) {
-            bits = co0 + 32 <= p.Cout ? *reinterpret_cast<const uint32_t*>(mp)
-                                      : (uint32_t)mp[0] | (co0 + 16 <= p.Cout ? (uint32_t)mp[1] << 8 : 0u) |
-                                            (co0 + 24 <= p.Cout ? (uint32_t)mp[2] << 16 : 0u);
-          } else if constexpr (HV == 2) {
-            bits = co0 + 16 <= p.Cout ? (uint32_t)*reinterpret_cast<const uint16_t*>(mp) : (uint32_t)mp[0];
-          } else {
-            bits = mp[0];
-          }
-#pragma unroll
-          for (int h = 0; h < HV; ++h) bpre[h] = (bits >> (8 * h)) & 0xffu;
-        }
-      }
-    }
+    addend_fetch<NR, POINTWISE, EPI, DT>(p, pre, m_base + mr * 16 + fr, co0);
   };
-  fetch_addend(0);
+  if (first != nullptr) pre = *first;
+  else fetch_addend(0);
 #pragma unroll
   for (int mr = 0; mr < MR; ++mr) {
     u32x4 acur[HV];
@@ -303,8 +326,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
     if constexpr (AHEAD) {
 #pragma unroll
       for (int h = 0; h < HV; ++h) {
-        acur[h] = apre[h];
-        bcur[h] = bpre[h];
+        acur[h] = pre.a[h];
+        bcur[h] = pre.b[h];
       }
       if (mr + 1 < MR) fetch_addend(mr + 1);
     }

@@ -282,6 +282,13 @@ void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) acc[nr][mr] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // the addend of the lane's first pixel block does not depend on the product: a pointwise layer
+  // (short K loop, no tap bookkeeping in registers) asks for it now - older than every tile load,
+  // so the counted waits of the ring retire it first
+  conv_epi::AddendAhead<NR, (DT == DT_F32 ? conv_epi::EPI_PLAIN : EPI)> ahead;
+  if constexpr (DT != DT_F32 && POINTWISE)
+    conv_epi::addend_fetch<NR, POINTWISE, EPI, DT>(p, ahead, m0 + wm * WM + (lane & 15),
+                                                   n0 + wn * WN + (lane >> 4) * 4 * NR);
   const int KT = (p.Ktotal + BK - 1) / BK;
   if constexpr (STAGES > 2) {
     // ---- ring of STAGES buffers ----------------------------------------------------------
@@ -382,7 +389,8 @@ void conv_igemm_kernel(const ConvParams p) {
 
   if constexpr (DT != DT_F32)
     conv_epi::conv_epilogue<MR, NR, POINTWISE, EPI, DT>(p, acc, m0 + wm * WM,
-                                                        n0 + wn * WN + fq * 4 * NR, mt, lane);
+                                                        n0 + wn * WN + fq * 4 * NR, mt, lane,
+                                                        POINTWISE ? &ahead : nullptr);
   else
     conv_epi::conv_epilogue_plain<DT, MR, NR, POINTWISE>(p, acc, m0 + wm * WM,
                                                          n0 + wn * WN + fq * 4 * NR, mt, lane);

@@ -244,6 +244,13 @@ void conv_pipe_kernel(const ConvParams p) {
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) acc[nr][mr] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // the addend of the lane's first pixel block does not depend on the product: a pointwise layer
+  // (short K loop, no tap bookkeeping in registers) asks for it now - older than every tile load,
+  // so the counted waits of the ring retire it first
+  conv_epi::AddendAhead<NR, EPI> ahead;
+  if constexpr (POINTWISE)
+    conv_epi::addend_fetch<NR, POINTWISE, EPI, DT>(p, ahead, m0 + wm * WM + (lane & 15),
+                                                   n0 + wn * WN + (lane >> 4) * 4 * NR);
   const int KT = (p.Ktotal + BK - 1) / BK;
   setup_tap();
   // prologue: the first STAGES - 1 steps
@@ -292,7 +299,8 @@ void conv_pipe_kernel(const ConvParams p) {
   }
 
   conv_epi::conv_epilogue<MR, NR, POINTWISE, EPI, DT>(p, acc, m0 + wm * WM,
-                                                      n0 + wn * WN + fq * 4 * NR, mt, lane);
+                                                      n0 + wn * WN + fq * 4 * NR, mt, lane,
+                                                      POINTWISE ? &ahead : nullptr);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int STAGES, int EPI, int DT>
