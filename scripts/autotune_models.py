@@ -3,12 +3,12 @@
 current GPU and writes the cache file used by `ops/autotune.py`.
 
     DTF_AUTOTUNE_OUT=gpurun_out/tuned_gfx950.json python scripts/autotune_models.py \
-        [--retune_rows] [model:batch[:dtype] ...]
+        [--retune_rows | --retune_addend] [model:batch[:dtype] ...]
                                    (default: resnet50:256 resnet56:128 resnet50:128 resnet20:128
                                     resnet50:256:fp16)
 
---retune_rows measures again the shapes the whole-rows 3x3 kernel can serve, entries of other
-shapes are kept.
+--retune_rows measures again the shapes the whole-rows kernels can serve, --retune_addend the
+launches whose epilogue adds another tensor; entries of other shapes are kept.
 """
 import os
 import sys
@@ -28,6 +28,8 @@ def main():
   jobs = [a for a in sys.argv[1:] if ":" in a] or ["resnet50:256", "resnet56:128",
                                                    "resnet50:128", "resnet20:128",
                                                    "resnet50:256:fp16"]
+  if "--retune_addend" in sys.argv:     # launches whose epilogue adds another tensor
+    autotune.RETUNE = lambda kind, desc: kind == "conv" and desc.get("addend") is not None
   if "--retune_rows" in sys.argv:
     autotune.RETUNE = lambda kind, desc: kind == "conv" and bool(autotune._rows_candidates(desc))
   dev = torch.device("cuda", 0)
