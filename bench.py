@@ -174,7 +174,7 @@ def main() -> int:
   if rank == 0:
     value = global_batch * a.steps / dt
     out = {
-        "metric": ("images/sec (whole node) ResNet-50 ImageNet-224 bs256/GPU" if a.model == "resnet50"
+        "metric": ("images/sec (whole node) ResNet-50 ImageNet-224 bs%d/GPU" % a.batch if a.model == "resnet50"
                    else "images/sec (whole node) %s CIFAR-10 bs%d/GPU" % (
                        {"resnet56": "ResNet-56", "resnet20": "ResNet-20"}[a.model], a.batch)),
         "value": round(value, 2), "unit": "images/sec", "n_gpus": a.gpus, "steps": a.steps,
