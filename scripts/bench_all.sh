@@ -1,5 +1,5 @@
 #!/bin/bash
-# Every bench.py configuration quoted in BASELINE.md / README.md, one JSON line each.
+# Every bench.py configuration quoted in the result tables, one JSON line each.
 cd "$(dirname "$0")/.."
 run() { echo "# bench.py $*"; timeout -k 10 300 python bench.py "$@" 2>/dev/null | tail -1; }
 run --steps 50 --warmup 10 && run --dtype fp32 --steps 20 --warmup 5 && run --dtype fp16 --steps 30 --warmup 10 && \
