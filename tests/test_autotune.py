@@ -60,3 +60,27 @@ def test_bundled_cache_is_well_formed():
       assert v["cfg"] in conv_plan.FWD_CFGS
     else:
       assert v["cfg"] % 16 in conv_plan.WGRAD_CFGS and v["splits"] >= 1
+
+
+def test_whole_rows_kernels_are_candidates_of_their_shapes_only():
+  """The whole-rows kernels (conv_rows.hip 48 - 54, conv_wgrad_rows.hip 192) join the candidate lists
+  of exactly the layers they serve; the bundled table uses them for ResNet-50 at batch 256."""
+  r56 = ConvGeom(256, 56, 56, 64, 3, 3, 64, 1, (1, 1, 1, 1))
+  r28 = ConvGeom(256, 28, 28, 128, 3, 3, 128, 1, (1, 1, 1, 1))
+  stem = ConvGeom(256, 224, 224, 3, 7, 7, 64, 2, (3, 3, 3, 3), mode="merged")
+  other = ConvGeom(256, 14, 14, 256, 3, 3, 256, 1, (1, 1, 1, 1))
+  strided = ConvGeom(256, 56, 56, 128, 3, 3, 128, 2, (0, 1, 0, 1))
+  assert {48, 50, 52, 53} <= set(autotune._fwd_candidates(r56.fwd(1, 2, 3)))
+  assert {49, 51} <= set(autotune._fwd_candidates(r28.fwd(1, 2, 3)))
+  assert 54 in autotune._fwd_candidates(stem.fwd(1, 2, 3))
+  for g in (other, strided):
+    assert not [c for c in autotune._fwd_candidates(g.fwd(1, 2, 3)) if 48 <= c < 56]
+  assert {48, 50, 52, 53} <= set(autotune._fwd_candidates(r56.dgrad(1, 2, 3)[0]))     # unit-stride data gradient
+  assert (192, autotune._wgrad_candidates(r56.wgrad(1, 2, 3))[0][1]) in autotune._wgrad_candidates(r56.wgrad(1, 2, 3))
+  for g in (r28, other, strided, stem):
+    assert not [c for c, _s in autotune._wgrad_candidates(g.wgrad(1, 2, 3)) if c == 192]
+  with open(autotune.CACHE_PATH) as f:
+    cache = json.load(f)
+  assert cache[autotune.signature("conv", r56.fwd(1, 2, 3, stats=4, stats_replicas=32))]["cfg"] in (48, 50, 52, 53)
+  assert cache[autotune.signature("conv", stem.fwd(1, 2, 3, stats=4, stats_replicas=32))]["cfg"] == 54
+  assert cache[autotune.signature("wgrad", r56.wgrad(1, 2, 3))]["cfg"] == 192
