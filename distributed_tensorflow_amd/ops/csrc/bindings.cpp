@@ -64,6 +64,8 @@ ConvParams conv_from_dict(const py::dict& d) {
   p.stats_replicas = get_or<int>(d, "stats_replicas", 0);
   p.stats_y = ptr<const bf16_t>(d, "stats_y", false);
   p.stats_mask = ptr<const uint8_t>(d, "stats_mask", false);
+  p.in_scale = ptr<const float>(d, "in_scale", false);
+  p.in_shift = ptr<const float>(d, "in_shift", false);
   p.pro.sums = ptr<const float>(d, "pro_sums", false);
   if (p.pro.sums) {
     p.pro.replicas = get<int>(d, "pro_replicas");
@@ -148,6 +150,8 @@ WgradParams wgrad_from_dict(const py::dict& d) {
   p.TJreal = get_or<int>(d, "TJreal", p.TJpad);
   p.splits = get_or<int>(d, "splits", 1);
   p.debug_plain_store = get_or<int>(d, "debug_plain_store", 0);
+  p.x_scale = ptr<const float>(d, "x_scale", false);
+  p.x_shift = ptr<const float>(d, "x_shift", false);
   p.rev = get_or<int>(d, "rev", 0);
   int pps = (p.P + p.splits - 1) / p.splits;
   pps = ((pps + 31) / 32) * 32;
@@ -271,8 +275,11 @@ Launch make_op(const std::string& kind, const py::dict& d, bool planned = false)
     auto tail = ptr<float>(d, "tail", false);
     // direction of the two sweeps: bit 0 reduction, bit 1 apply run back to front
     const int rev = get_or<int>(d, "rev_reduce", 0) | (get_or<int>(d, "rev_apply", 0) << 1);
+    // ReLU mask from the sign of y * relu_scale + relu_shift instead of mask bits / z
+    auto rsc = ptr<const float>(d, "relu_scale", false); auto rsh = ptr<const float>(d, "relu_shift", false);
     return [=](hipStream_t s) {
-      launch_bn_bwd(dz, y, z, mask, mean, inv, gamma, dgamma, dbeta, dy, dres, ws, P, C, pre, tail, rev, dt, s);
+      launch_bn_bwd(dz, y, z, mask, mean, inv, gamma, dgamma, dbeta, dy, dres, ws, P, C, pre, tail, rev, rsc, rsh,
+                    dt, s);
     };
   }
   if (kind == "bn_bwd_dual") {

@@ -383,6 +383,9 @@ struct BnBwdArgs {
   // the rows, stores dgamma / dbeta and leaves rows and ticket zeroed for the next launch.
   unsigned int* ticket;
   int rev_reduce, rev_apply;   // passes of the reduction / apply sweep run back to front
+  // ReLU mask from the sign of the recomputed value y * relu_scale[c] + relu_shift[c] (the forward
+  // pass normalised this tensor inside its consumer's tile and wrote neither z nor mask bits)
+  const float* relu_scale; const float* relu_shift;
 };
 
 constexpr int TAIL_REPLICAS = 8;
@@ -403,13 +406,21 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
   for (int i = 0; i < 16; ++i) part[i] = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) part2[i] = 0.f;
-  const int mode = a.mask ? 2 : (a.z ? 1 : 0);
+  const int mode = a.relu_scale ? 3 : (a.mask ? 2 : (a.z ? 1 : 0));
+  float rsc[8], rsh[8];
+  if (mode == 3) {
+    load8(a.relu_scale + chunk * 8, rsc);
+    load8(a.relu_shift + chunk * 8, rsh);
+  }
   auto accumulate = [&](const Raw8<DT>& gv, const Raw8<DT>& yq, const Raw8<DT>& zq, uint32_t bits,
                         const Raw8<DT>& y2q) {
     float g[8], yv[8];
     unpack8<DT>(gv, g);
     unpack8<DT>(yq, yv);
-    if (mode == 2) {
+    if (mode == 3) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) g[c] = yv[c] * rsc[c] + rsh[c] > 0.f ? g[c] : 0.f;
+    } else if (mode == 2) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) g[c] = (bits >> c) & 1u ? g[c] : 0.f;
     } else if (mode == 1) {
@@ -581,13 +592,21 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdArgs a) {
       c22[c] *= invP;
     }
   }
-  const int mode = a.mask ? 2 : (a.z ? 1 : 0);
+  const int mode = a.relu_scale ? 3 : (a.mask ? 2 : (a.z ? 1 : 0));
+  float rsc[8], rsh[8];
+  if (mode == 3) {
+    load8(a.relu_scale + chunk * 8, rsc);
+    load8(a.relu_shift + chunk * 8, rsh);
+  }
   auto finish = [&](const Raw8<DT>& gv, const Raw8<DT>& yq, const Raw8<DT>& zq, uint32_t bits, size_t off,
                     const Raw8<DT>& y2q) {
     float g[8], yv[8];
     unpack8<DT>(gv, g);
     unpack8<DT>(yq, yv);
-    if (mode == 2) {
+    if (mode == 3) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) g[c] = yv[c] * rsc[c] + rsh[c] > 0.f ? g[c] : 0.f;
+    } else if (mode == 2) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) g[c] = (bits >> c) & 1u ? g[c] : 0.f;
     } else if (mode == 1) {
@@ -1154,14 +1173,17 @@ size_t bn_tail_floats() { return 16 + 2 * (size_t)TAIL_REPLICAS * 2 * 2048; }
 void launch_bn_bwd(const void* dz, const void* y, const void* z, const uint8_t* mask,
                    const float* mean, const float* invstd, const float* gamma, float* dgamma,
                    float* dbeta, void* dy, void* dres, float* ws, int P, int C,
-                   int pre_replicas, float* tail, int rev, int dt, hipStream_t s) {
+                   int pre_replicas, float* tail, int rev, const float* relu_scale,
+                   const float* relu_shift, int dt, hipStream_t s) {
   check_channels(C, P);
   if (pre_replicas < 0) throw std::invalid_argument("bn_bwd: negative replica count");
+  if ((relu_scale == nullptr) != (relu_shift == nullptr) || (relu_scale && (mask || z)))
+    throw std::invalid_argument("bn_bwd: relu_scale / relu_shift come together, instead of mask / z");
   const int G = pre_replicas > 0 ? pre_replicas : reduce_grid(P, C);
   BnBwdArgs a{dz, y, z, mask, mean, invstd, gamma, dgamma, dbeta, dy, dres, ws, G, P, C,
               pre_replicas > 0 ? 1 : 0,
               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-              rev & 1, (rev >> 1) & 1};
+              rev & 1, (rev >> 1) & 1, relu_scale, relu_shift};
   static const bool fold_ok = [] {
     const char* e = std::getenv("DTF_BN_FOLD_FINALIZE");
     return !(e && e[0] == '0');

@@ -539,10 +539,14 @@ void launch_conv_igemm(const ConvParams& p, int cfg, hipStream_t stream) {
   } else if (p.pro.sums || p.bpro.sums) {
     throw std::invalid_argument("conv: a BatchNorm prologue needs a tile configuration of conv_halo.hip (40..47)");
   }
+  if ((p.in_scale == nullptr) != (p.in_shift == nullptr))
+    throw std::invalid_argument("conv: in_scale / in_shift come together");
   if (cfg >= 48 && cfg < 56) {
     if (launch_conv_rows(p, cfg, stream)) return;
     cfg = rows_fallback_cfg(cfg);
   }
+  if (p.in_scale)
+    throw std::invalid_argument("conv: normalising the input inside the tile needs a whole-rows 3x3 configuration (48..53) that serves the layer");
   if (cfg >= 16 && cfg < 32) {
     if (p.dt != DT_F32 && launch_conv_pipe(p, cfg, stream)) return;
     cfg = pipe_fallback_cfg(cfg);

@@ -62,6 +62,12 @@ struct ConvParams {
   // elements whose bit is set are added (the ReLU mask of a residual branch's gradient)
   const uint8_t* addend_mask = nullptr;
   const float* bias = nullptr;     // optional per-output-channel bias
+  // Whole-rows kernels only (conv_rows.hip): `in` is the raw output of the layer in front and the
+  // training BatchNorm + ReLU between the two layers is applied inside the halo tile,
+  // x := max(in * in_scale[c] + in_shift[c], 0), once per element, so that the normalised tensor is
+  // never written (scale / shift: the per-channel constants the BatchNorm's finalize step stored)
+  const float* in_scale = nullptr;
+  const float* in_shift = nullptr;
   // Inference epilogue (folded BatchNorm): out = relu?(acc * scale[co] + bias[co] (+ addend)).
   // `scale` selects it; `bias` then carries the shift and `relu` the activation.
   const float* scale = nullptr;
@@ -125,6 +131,10 @@ struct WgradParams {
   // whole-rows kernel only: wgrad_rows_workspace_floats() floats the blocks store their partial
   // gradients to (summed into `dw` by a second launch); null: every block adds to `dw` atomically
   float* ws = nullptr;
+  // whole-rows kernel only: x := max(x * x_scale[c] + x_shift[c], 0) inside the halo tile (the
+  // forward launch normalised its input the same way, see ConvParams::in_scale)
+  const float* x_scale = nullptr;
+  const float* x_shift = nullptr;
   FastDiv divOW, divOH, divCpad, divTJpad;
 };
 

@@ -152,6 +152,46 @@ void conv_rows_kernel(const ConvParams p) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(halo + (it * NW + wave) * 1024), 16, 0, 0);
   }
 
+  // ---- 1b. BatchNorm + ReLU of the layer in front, inside the tile: every thread transforms the
+  // 16-byte positions it fetched (always the same eight channels: the chunk index of a position
+  // depends on lane and wave only), out-of-image pixels stay zero.  The ring's first loads are
+  // issued behind this pass so that the counted wait below covers the halo loads alone.
+  if (p.in_scale != nullptr) {
+    constexpr int CH_PERIOD = CPP / 2;               // bank rows after which the chunk pair repeats
+    static_assert((NW * 4) % CH_PERIOD == 0, "a thread's positions share their channel chunk");
+    const int ch = ((((wave * 4 + (lane >> 4)) % CH_PERIOD) << 1) | ((lane & 15) >> 3));
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = p.in_scale[ch * 8 + e];
+      sh[e] = p.in_shift[ch * 8 + e];
+    }
+    rows_wait_vmcnt<0>();                            // own halo loads have landed (own positions only)
+#pragma unroll
+    for (int it = 0; it < HROUNDS; ++it) {
+      const int q = (it * NW + wave) * 64 + lane;
+      const int brow = q >> 4, slot = q & 15;
+      const int grp = brow / (CPP / 2);
+      const int hp = grp * 8 + (slot & 7);
+      const int hr = hp / HW, hc = hp - hr * HW;
+      const int hi = r0 + hr + org_h, wi = hc + org_w;
+      const bool ok = hp < HPIX && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)W;
+      if (ok) {
+        u32x4* cell = reinterpret_cast<u32x4*>(halo + (size_t)q * 16);
+        const u32x4 v = *cell;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = fmaxf(lo16<DT>(w[j]) * sc[2 * j] + sh[2 * j], 0.f);
+          const float hi2 = fmaxf(hi16<DT>(w[j]) * sc[2 * j + 1] + sh[2 * j + 1], 0.f);
+          o[j] = pack2<DT>(lo, hi2);
+        }
+        *cell = u32x4{o[0], o[1], o[2], o[3]};
+      }
+    }
+  }
+
   // ---- 2. weight ring: lane l of a wave instruction lands at row l/4, slot l%4 of the wave's 16
   // rows; XOR swizzle of the fragment reads applied to the source chunk (conv_igemm.hip) ----------
   const int lrow = tid >> 2;                         // 0 .. 63
@@ -381,7 +421,7 @@ void conv_stem_rows_kernel(const ConvParams p, int tiles_per_block, int ntiles) 
 }
 
 bool stem_rows_supports(const ConvParams& p) {
-  return p.dt != DT_F32 && !p.scale && !p.bias && !p.addend && !p.stats_y && !p.pro.sums && !p.bpro.sums &&
+  return p.dt != DT_F32 && !p.in_scale && !p.scale && !p.bias && !p.addend && !p.stats_y && !p.pro.sums && !p.bpro.sums &&
          p.TI == 7 && p.TJ == 1 && p.Ctap == 32 && p.Cpix == 4 && p.ISH == 2 && p.ISW == 2 &&
          p.dh0 == 0 && p.dw0 == 0 && p.dhs == 1 && p.wsi == 32 && p.OW == STEM_OW && p.OH % 2 == 0 &&
          p.OSH == 1 && p.OSW == 1 && p.OOH == 0 && p.OOW == 0 && p.OHfull == p.OH && p.OWfull == p.OW &&

@@ -462,10 +462,14 @@ void validate_wgrad_params(const WgradParams& p) {
 // cfg 192: the whole-rows kernel of conv_wgrad_rows.hip.
 void launch_conv_wgrad(const WgradParams& p, int cfg, hipStream_t stream) {
   validate_wgrad_params(p);
+  if ((p.x_scale == nullptr) != (p.x_shift == nullptr))
+    throw std::invalid_argument("conv_wgrad: x_scale / x_shift come together");
   if (cfg == WGRAD_ROWS_CFG) {
     if (launch_conv_wgrad_rows(p, cfg, stream)) return;
     cfg = 0;                   // a descriptor the whole-rows kernel cannot serve: the 128x128 tile
   }
+  if (p.x_scale)
+    throw std::invalid_argument("conv_wgrad: normalising X inside the tile needs the whole-rows kernel (cfg 192) to serve the layer");
   if (cfg < 0 || cfg >= 192 || (cfg % 64) >= 48)
     throw std::invalid_argument("conv_wgrad: unknown tile config");
   const int stages = 2 + cfg / 64;

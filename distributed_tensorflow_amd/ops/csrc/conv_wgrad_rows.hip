@@ -67,14 +67,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(const WgradPara
   constexpr int YBYTES = PIX * COUT * 2;
   constexpr int HROUNDS = HBYTES / 4096;             // DMA rounds: 256 threads x 16 bytes
   static_assert(PIX % 32 == 0 && HBYTES % 4096 == 0 && W + 2 <= PITCH, "tile shape");
-  static_assert(2 * (HBYTES + YBYTES) <= 160 * 1024, "two blocks per compute unit");
+  static_assert(2 * (HBYTES + YBYTES + 2 * C * 4) <= 160 * 1024, "two blocks per compute unit");
   typedef uint16_t T;
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
 
-  __shared__ __attribute__((aligned(16))) uint8_t smem[HBYTES + YBYTES];
+  constexpr int TBYTES = 2 * C * 4;                   // scale / shift of an input normalised in the tile
+  __shared__ __attribute__((aligned(16))) uint8_t smem[HBYTES + YBYTES + TBYTES];
   uint8_t* halo = smem;
   uint8_t* ys = smem + HBYTES;
+  float* xtab = reinterpret_cast<float*>(smem + HBYTES + YBYTES);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T* __restrict__ gx = reinterpret_cast<const T*>(p.x);
@@ -94,6 +96,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(const WgradPara
   const int yrow = tid >> 3;
   const int ych = ((((tid & 7) >> 1) ^ swz64(yrow)) << 1) | (tid & 1);      // logical 16-byte chunk
 
+  if (p.x_scale != nullptr) {                        // the forward launch normalised X inside its tile
+    if (tid < C) {
+      xtab[tid] = p.x_scale[tid];
+      xtab[C + tid] = p.x_shift[tid];
+    }
+    dma_wait_all();
+    __syncthreads();
+  }
   const int tiles_h = p.H / TR;
   const int t0 = blockIdx.x * tiles_per_block;
   const int t1 = min(t0 + tiles_per_block, ntiles);
@@ -124,6 +134,32 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(const WgradPara
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ys + s * 4096 + wave * 1024), 16, 0, 0);
     }
     dma_wait_all();
+    if (p.x_scale != nullptr) {
+      // BatchNorm + ReLU of the layer in front on the positions this thread fetched itself
+      // (out-of-image pixels stay zero), as the forward launch did in its halo tile
+#pragma unroll 2
+      for (int it = 0; it < HROUNDS; ++it) {
+        const int u = (it * 4 + wave) * 64 + lane;
+        const int hp = u >> 3, s16 = u & 7;
+        const int ch16 = ((((s16 >> 1) ^ swz64(hp)) << 1) | (s16 & 1));
+        const int hr = hp / PITCH, hc = hp % PITCH;
+        const int hi = r0 + hr - 1, wi = hc - 1;
+        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)W) {
+          u32x4* cell = reinterpret_cast<u32x4*>(halo + (size_t)u * 16);
+          const u32x4 v = *cell;
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(xtab + ch16 * 8);
+          const f32x4 s1 = *reinterpret_cast<const f32x4*>(xtab + ch16 * 8 + 4);
+          const f32x4 h0 = *reinterpret_cast<const f32x4*>(xtab + C + ch16 * 8);
+          const f32x4 h1 = *reinterpret_cast<const f32x4*>(xtab + C + ch16 * 8 + 4);
+          u32x4 o;
+          o.x = pack2<DT>(fmaxf(lo16<DT>(v.x) * s0[0] + h0[0], 0.f), fmaxf(hi16<DT>(v.x) * s0[1] + h0[1], 0.f));
+          o.y = pack2<DT>(fmaxf(lo16<DT>(v.y) * s0[2] + h0[2], 0.f), fmaxf(hi16<DT>(v.y) * s0[3] + h0[3], 0.f));
+          o.z = pack2<DT>(fmaxf(lo16<DT>(v.z) * s1[0] + h1[0], 0.f), fmaxf(hi16<DT>(v.z) * s1[1] + h1[1], 0.f));
+          o.w = pack2<DT>(fmaxf(lo16<DT>(v.w) * s1[2] + h1[2], 0.f), fmaxf(hi16<DT>(v.w) * s1[3] + h1[3], 0.f));
+          *cell = o;
+        }
+      }
+    }
     __syncthreads();
 
     // ---- nine taps x KS steps out of LDS ----------------------------------------------------------

@@ -40,7 +40,8 @@ void launch_bn_infer(const void* y, const void* res, void* z, const float* gamma
 void launch_bn_bwd(const void* dz, const void* y, const void* z, const uint8_t* mask,
                    const float* mean, const float* invstd, const float* gamma, float* dgamma,
                    float* dbeta, void* dy, void* dres, float* ws, int P, int C,
-                   int pre_replicas, float* tail, int rev, int dt, hipStream_t s);
+                   int pre_replicas, float* tail, int rev, const float* relu_scale, const float* relu_shift, int dt,
+                   hipStream_t s);
 // `rev`: bit 0 - the reduction sweep, bit 1 - the apply sweep walks the rows back to front (the
 // launch plan alternates directions so that a sweep starts on the rows still in the memory-side
 // cache; `rev` of the forward launch is the apply sweep's direction).

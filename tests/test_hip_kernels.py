@@ -1239,3 +1239,108 @@ def test_stem_whole_rows_kernel(N, dtype):
   small = ConvGeom(N, 64, 64, 3, 7, 7, 64, 2, (3, 3, 3, 3), mode="merged", dt=dti)
   probe = torch.zeros(16, device=dev)
   assert not native.ext().conv_rows_serves(small.fwd(probe.data_ptr(), probe.data_ptr(), probe.data_ptr(), cfg=54))
+
+
+def _affine_relu(x, scale, shift):
+  """What the BatchNorm apply sweep would have written: relu(fma(x, scale, shift)) in fp32, rounded
+  (the product is not rounded on its own: computed in double and rounded once)."""
+  return torch.relu((x.double() * scale.double() + shift.double()).float()).to(x.dtype)
+
+
+@pytest.mark.parametrize("case,cfg", [((3, 56, 56, 64, 3, 64, 1), 52), ((2, 56, 56, 64, 3, 64, 1), 48),
+                                      ((3, 28, 28, 128, 3, 128, 1), 49), ((2, 28, 28, 128, 3, 128, 1), 51)])
+def test_whole_rows_kernels_normalise_their_input_inside_the_tile(case, cfg):
+  """conv_rows.hip with `in_scale` / `in_shift`: BatchNorm + ReLU of the layer in front applied to the halo
+  tile in LDS.  The result equals, bit for bit, the same launch on a tensor normalised beforehand
+  (padding pixels stay zero, not relu(shift)); other tiles refuse such a descriptor."""
+  native = _native()
+  N, H, W, Cin, K, Cout, stride = case
+  dev = torch.device("cuda")
+  gen = torch.Generator(device="cpu").manual_seed(cfg)
+  pad = same_padding(H, K, stride) + same_padding(W, K, stride)
+  g = ConvGeom(N, H, W, Cin, K, K, Cout, stride, pad)
+  y = _bf(torch.randn(N, H, W, Cin, generator=gen)).to(dev)
+  scale = (torch.rand(Cin, generator=gen) + 0.5).to(dev)
+  shift = (torch.randn(Cin, generator=gen) * 0.5 + 0.3).to(dev)     # mostly positive: relu(shift) != 0
+  a = _affine_relu(y, scale, shift)
+  w = (torch.randn(K, K, Cin, Cout, generator=gen) * 0.05).to(dev)
+  wf = _pack(native, g, w, "fwd")
+  out_ref = torch.zeros(g.output_shape, dtype=torch.bfloat16, device=dev)
+  out = torch.zeros_like(out_ref)
+  stats_ref = torch.zeros(32, 2, Cout, device=dev)
+  stats = torch.zeros_like(stats_ref)
+  native.run_op("conv", g.fwd(a.data_ptr(), wf.data_ptr(), out_ref.data_ptr(), cfg=cfg,
+                              stats=stats_ref.data_ptr(), stats_replicas=32))
+  d = dict(g.fwd(y.data_ptr(), wf.data_ptr(), out.data_ptr(), cfg=cfg, stats=stats.data_ptr(), stats_replicas=32),
+           in_scale=scale.data_ptr(), in_shift=shift.data_ptr())
+  native.run_op("conv", d)
+  torch.cuda.synchronize()
+  assert torch.equal(out, out_ref)
+  assert torch.allclose(stats.sum(0), stats_ref.sum(0), rtol=1e-4, atol=1e-2)
+  ref = _ref_conv(a.float(), _bf(w).float(), stride, pad)
+  assert (out.float() - ref).abs().max().item() <= 0.02 * ref.abs().max().item() + 1e-2
+  with pytest.raises(ValueError):
+    native.run_op("conv", dict(d, cfg=30))
+
+
+@pytest.mark.parametrize("N", [3, 2])
+def test_whole_rows_weight_gradient_normalises_x_inside_the_tile(N):
+  """conv_wgrad_rows.hip with `x_scale` / `x_shift` against the same launch on a normalised X."""
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator(device="cpu").manual_seed(N)
+  g = ConvGeom(N, 56, 56, 64, 3, 3, 64, 1, (1, 1, 1, 1))
+  y = _bf(torch.randn(N, 56, 56, 64, generator=gen)).to(dev)
+  scale = (torch.rand(64, generator=gen) + 0.5).to(dev)
+  shift = (torch.randn(64, generator=gen) * 0.5 + 0.3).to(dev)
+  a = _affine_relu(y, scale, shift)
+  dy = _bf(torch.randn(N, 56, 56, 64, generator=gen)).to(dev)
+  dw_ref = torch.zeros(3, 3, 64, 64, device=dev)
+  dw = torch.zeros_like(dw_ref)
+  native.run_op("wgrad", g.wgrad(a.data_ptr(), dy.data_ptr(), dw_ref.data_ptr(), cfg=192, splits=1))
+  d = dict(g.wgrad(y.data_ptr(), dy.data_ptr(), dw.data_ptr(), cfg=192, splits=1),
+           x_scale=scale.data_ptr(), x_shift=shift.data_ptr())
+  native.run_op("wgrad", d)
+  torch.cuda.synchronize()
+  assert torch.equal(dw, dw_ref)               # one split: a fixed summation order in both launches
+  wr = torch.zeros(3, 3, 64, 64, device=dev).requires_grad_(True)
+  _ref_conv(a.float(), wr, 1, (1, 1, 1, 1)).backward(dy.float())
+  assert (dw - wr.grad).abs().max().item() <= 2e-3 * wr.grad.abs().max().item() + 1e-3
+  with pytest.raises(ValueError):
+    native.run_op("wgrad", dict(d, cfg=1))
+
+
+@pytest.mark.parametrize("P,C", [(70001, 64), (40003, 256)])
+def test_batchnorm_backward_takes_its_relu_mask_from_the_recomputed_value(P, C):
+  """bn_bwd with `relu_scale` / `relu_shift` (mask = y * scale + shift > 0, for a layer whose forward
+  output was never written) equals bn_bwd with the mask bits of the same predicate."""
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator(device="cpu").manual_seed(C)
+  y = _bf(torch.randn(P, C, generator=gen)).to(dev)
+  dz = _bf(torch.randn(P, C, generator=gen)).to(dev)
+  gamma = (torch.rand(C, generator=gen) + 0.5).to(dev)
+  beta = (torch.randn(C, generator=gen) * 0.2).to(dev)
+  mean = y.float().mean(0)
+  invstd = torch.rsqrt(y.float().var(0, unbiased=False) + 1e-5)
+  saved = torch.cat([mean, invstd, gamma * invstd, beta - mean * gamma * invstd]).contiguous()
+  scale, shift = saved[2 * C:3 * C], saved[3 * C:]
+  open_ = (y.float() * scale + shift) > 0
+  bits = open_.view(P, C // 8, 8).to(torch.int32)
+  mask = (bits << torch.arange(8, device=dev)).sum(-1).to(torch.uint8).contiguous()
+  ws = torch.zeros(native.ext().bn_workspace_floats(), device=dev)
+  outs = []
+  for kw in (dict(mask=mask.data_ptr()), dict(mask=None, relu_scale=saved.data_ptr() + 8 * C,
+                                              relu_shift=saved.data_ptr() + 12 * C)):
+    dgamma, dbeta = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dy = torch.empty(P, C, dtype=torch.bfloat16, device=dev)
+    native.run_op("bn_bwd", dict(dz=dz.data_ptr(), y=y.data_ptr(), z=None, mean=saved.data_ptr(),
+                                 invstd=saved.data_ptr() + 4 * C, gamma=gamma.data_ptr(), dgamma=dgamma.data_ptr(),
+                                 dbeta=dbeta.data_ptr(), dy=dy.data_ptr(), dres=None, ws=ws.data_ptr(), P=P, C=C,
+                                 **kw))
+    torch.cuda.synchronize()
+    outs.append((dgamma, dbeta, dy))
+  for a, b in zip(*outs):
+    assert torch.equal(a, b)
+  g = dz.float() * open_
+  assert torch.allclose(outs[1][1], g.sum(0), rtol=1e-2, atol=5e-2)
