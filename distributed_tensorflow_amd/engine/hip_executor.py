@@ -385,6 +385,49 @@ class HipExecutor:
           self._bn_prologue[b.name] = u[0]
           self._prologue_of[u[0].name] = b
 
+    # ---- BatchNorm + ReLU applied inside the consumer's tile (whole-rows kernels) --------------
+    # Where the only consumer of a BatchNorm is a 3x3 layer that the whole-rows kernels serve in the
+    # forward pass AND in the weight gradient, both stage their operand in LDS once per element: the
+    # scale / shift / ReLU runs there (`in_scale` of the convolution, `x_scale` of the weight
+    # gradient) and the normalised tensor is never written or read - the apply sweep (one read, one
+    # write of the tensor) disappears, the backward sweeps take the ReLU mask from the sign of
+    # the recomputed value.  Large tensors only: a small one has its backward statistics
+    # accumulated by the data gradient, which needs the mask bits of the apply sweep
+    # (DTF_BN_IN_TILE=0: never, 2: whatever the size).
+    self._bn_in_tile: Dict[str, Op] = {}        # BatchNorm name -> consumer convolution
+    self._in_tile_of: Dict[str, Op] = {}        # convolution name -> BatchNorm
+    self._in_tile_cfg: Dict[str, Tuple[int, int]] = {}   # convolution name -> (forward, weight-gradient) tile
+    in_tile = os.environ.get("DTF_BN_IN_TILE", "1")
+    if self.fused_bn_stats and self.dt in (0, 1) and in_tile != "0":
+      users = {}
+      for op in spec.ops:
+        for t in op.inputs:
+          users.setdefault(t, []).append(op)
+      small = int(os.environ.get("DTF_BWD_STATS_SMALL_BYTES", self.BWD_STATS_SMALL_BYTES))
+      probe = torch.zeros(16, device=self.device)
+      pp = probe.data_ptr()
+      for b in bn_ops:
+        u = users.get(b.output, [])
+        if (b.name not in self._bn_stats_off or b.name in self._bn_pool or b.name in self._bn_lazy
+            or b.name in self._bn_prologue or not b.attrs["relu"] or len(b.inputs) != 1
+            or len(u) != 1 or u[0].kind != "conv" or b.output == spec.logits_name):
+          continue
+        if in_tile != "2" and self.fused_bn_bwd_stats and acts[b.output].numel() * self.esize <= small:
+          continue
+        g = geoms[u[0].name]
+        fd = autotune.apply("conv", g.fwd(pp, pp, pp, stats=pp if u[0].output in self._stats_of_conv else None,
+                                          stats_replicas=self.STATS_REPLICAS))
+        wd = autotune.apply("wgrad", g.wgrad(pp, pp, pp))
+        if in_tile == "2":               # tests: the whole-rows tiles wherever they serve the layer
+          fd = next((dict(fd, cfg=c) for c in (52, 49) if native.ext().conv_rows_serves(dict(fd, cfg=c))), fd)
+          wd = dict(wd, cfg=192)
+        if (48 <= fd.get("cfg", 0) < 54 and native.ext().conv_rows_serves(fd)
+            and wd.get("cfg") == 192 and native.ext().wgrad_rows_serves(wd)):
+          self._bn_in_tile[b.name] = u[0]
+          self._in_tile_of[u[0].name] = b
+          self._in_tile_cfg[u[0].name] = (fd["cfg"], wd["cfg"])
+      self._keep.append(probe)
+
     ext = native.ext()
     self.fwd_plan = _TypedPlan(ext.Plan(), self.dt)
     self.eval_plan = _TypedPlan(ext.Plan(), self.dt)
@@ -755,6 +798,17 @@ class HipExecutor:
                  pro_res=acts[b.inputs[1]].data_ptr() if len(b.inputs) > 1 else None)
         d["cfg"] = 42 if g.Cout <= 16 else 45       # 64-pixel tiles always hold whole image rows
         self._add(plan, "conv", d, b.name + "+" + op.name)
+      elif op.kind == "conv" and training and op.name in self._in_tile_of:
+        # the BatchNorm in front is applied inside this layer's halo tile: it reads the raw output
+        # of the layer before and the constants the BatchNorm's finalize launch stored
+        b = self._in_tile_of[op.name]
+        g = self.geoms[op.name]
+        sp = self.bn_saved.data_ptr() + 4 * self._bn_off[b.name]
+        cb = b.attrs["channels"]
+        d = g.fwd(acts[b.inputs[0]].data_ptr(), self._wf_ptr(op.name), acts[op.output].data_ptr(),
+                  stats=self._stats_of_conv.get(op.output), stats_replicas=self.STATS_REPLICAS)
+        d.update(in_scale=sp + 8 * cb, in_shift=sp + 12 * cb, cfg=self._in_tile_cfg[op.name][0])
+        self._add(plan, "conv", d, b.name + "+" + op.name)
       elif op.kind == "conv":
         g = self.geoms[op.name]
         st = self._stats_of_conv.get(op.output) if training else None
@@ -796,7 +850,10 @@ class HipExecutor:
               else self.bn_ws.data_ptr()
           mask = self._bn_mask[op.name].data_ptr() if op.name in self._bn_mask else None
           extra = {}
-          if op.name in self._bn_lazy:
+          if op.name in self._bn_in_tile:
+            extra["apply"] = 0           # statistics only: applied inside the consumer's tile
+            mask = None
+          elif op.name in self._bn_lazy:
             # projection shortcut: statistics only; the block's last BatchNorm normalises this
             # layer's input on the fly when it adds the residual
             extra["apply"] = 0
@@ -967,6 +1024,7 @@ class HipExecutor:
       layer's backward reductions (sum g, sum g*y) so that its reduction sweep disappears."""
       src = producer.get(xname)
       if (uses_left.get(xname, 0) != 1 or src is None or src.kind != "bn"
+          or src.name in self._bn_in_tile        # no mask bits: its apply sweep never ran
           or src.name not in self._bn_bwd_stats_off or cin % 8
           or cin != src.attrs["channels"]):
         return {}
@@ -1108,7 +1166,8 @@ class HipExecutor:
           if dout is None:
             raise RuntimeError("residual BatchNorm %s fed by a deferred gradient" % op.name)
           pending[rname] = (dout, mask_ptr)
-        if self._bwd_prologue_ok(op, producer.get(xname), first_conv, prologue_limit):
+        if op.name not in self._bn_in_tile and \
+            self._bwd_prologue_ok(op, producer.get(xname), first_conv, prologue_limit):
           # small layer: the data gradient of the convolution in front of this BatchNorm applies
           # the backward formula to dz on its way into LDS and writes dy on the side
           bwd_pro[xname] = dict(
@@ -1128,8 +1187,12 @@ class HipExecutor:
         if op.name not in self._bn_pre_stats:
           rr = self._sweep_dir([(dz_ptr, nb), (x.data_ptr(), nb)])
         ra = self._sweep_dir([(dz_ptr, nb), (x.data_ptr(), nb), (dy.data_ptr(), nb)])
+        relu_from_y = {}
+        if op.name in self._bn_in_tile:
+          mask_ptr = None
+          relu_from_y = dict(relu_scale=mean_p + 8 * C, relu_shift=mean_p + 12 * C)
         plan.add("bn_bwd", dict(
-            rev_reduce=rr, rev_apply=ra,
+            rev_reduce=rr, rev_apply=ra, **relu_from_y,
             dz=dz_ptr, y=x.data_ptr(), z=None, mask=mask_ptr,
             mean=mean_p, invstd=inv_p,
             gamma=self._var_ptr(op.name + "/gamma"),
@@ -1175,9 +1238,17 @@ class HipExecutor:
         # the data gradient (so that it starts next to the memory-bound BatchNorm sweeps of the
         # layer below instead of next to a second matrix kernel) measured 21.9 against 21.5 ms:
         # the sweeps are shorter than a weight gradient, the lane falls behind and ends alone.
-        self._add_wgrad(plan, g.wgrad(acts[xname].data_ptr(), dout.data_ptr(),
-                                      self._var_ptr(op.name + "/kernel", "grad")),
-                        op.name + "/wgrad")
+        wdesc = g.wgrad(acts[xname].data_ptr(), dout.data_ptr(),
+                        self._var_ptr(op.name + "/kernel", "grad"))
+        if op.name in self._in_tile_of:
+          # its input was normalised inside the forward launch's tile and never written: the
+          # weight gradient reads the raw tensor and applies the same constants in its tile
+          b = self._in_tile_of[op.name]
+          sp = self.bn_saved.data_ptr() + 4 * self._bn_off[b.name]
+          cb = b.attrs["channels"]
+          wdesc.update(x=acts[b.inputs[0]].data_ptr(), x_scale=sp + 8 * cb, x_shift=sp + 12 * cb,
+                       cfg=self._in_tile_cfg[op.name][1])
+        self._add_wgrad(plan, wdesc, op.name + "/wgrad")
         if (op is not first_conv and g.has_empty_parities() and defer_ok
             and uses_left.get(xname, 0) > 1 and xname not in written and xname not in pending
             and acts[xname].numel() * self.esize > small):

@@ -16,7 +16,7 @@ the stored gradient of its output - and compared with what the plan left behind:
 Tensors the plan never materialises (the normalised shortcut of a projection block, the stem's
 full-resolution activation, masked residual gradients) are recomputed from their producers /
 consumers the same way.  Errors do not accumulate across layers, so the bounds are tight:
-5e-3 relative L2 in fp32 (each ReLU mask bit that flips at a pre-activation within rounding of
+5e-3 relative L2 in fp32 for variables and 8e-3 for activation gradients (each ReLU mask bit that flips at a pre-activation within rounding of
 zero moves a gradient tensor of a million elements by about 1e-3 of its norm; a wiring mistake
 moves it by its whole norm), 1e-2 in bf16 (one rounding of the stored result).
 """
@@ -45,7 +45,7 @@ class _Teacher:
     # forward tensors the plan does not write: outputs of lazily normalised shortcut BatchNorms
     # and of a BatchNorm fused with its max-pool
     self.virtual = {b.output for b in spec.ops if b.kind == "bn" and
-                    (b.name in hx._bn_lazy or b.name in hx._bn_pool)}
+                    (b.name in hx._bn_lazy or b.name in hx._bn_pool or b.name in hx._bn_in_tile)}
     self._act, self._grad, self._vjp = {}, {}, {}
 
   # -- activations (NCHW fp32) ---------------------------------------------------------------
@@ -133,9 +133,13 @@ class _Teacher:
     ("resnet20", 16, "fp32", 5e-3), ("resnet50", 8, "fp32", 5e-3),
     ("resnet20", 16, "bf16", 1e-2), ("resnet50", 8, "bf16", 1e-2),
 ])
-def test_every_layer_backward_from_the_executors_own_buffers(name, batch, dtype, tol):
+def test_every_layer_backward_from_the_executors_own_buffers(name, batch, dtype, tol, monkeypatch):
   from distributed_tensorflow_amd.engine.hip_executor import HipExecutor
   from distributed_tensorflow_amd.engine.params import ParamStore
+  if name == "resnet50" and dtype == "bf16":
+    # also the BatchNorms that are applied inside their consumer's tile (at this batch size their
+    # tensors are small and would otherwise keep the apply sweep)
+    monkeypatch.setenv("DTF_BN_IN_TILE", "2")
   torch.backends.cudnn.allow_tf32 = False
   torch.backends.cuda.matmul.allow_tf32 = False
   spec = getattr(models, name)()
@@ -173,7 +177,12 @@ def test_every_layer_backward_from_the_executors_own_buffers(name, batch, dtype,
     if got is None or tname == "input":
       continue
     r = _rel(got, t.expected_grad(tname))
-    assert r <= tol, (tname, r)
+    # the statistics come out of the convolution epilogues through float atomics: their last bits
+    # vary from run to run and with them a handful of ReLU mask bits at pre-activations within
+    # rounding of zero (~1e-3 of a gradient tensor's norm per flipped bit)
+    assert r <= max(tol, 8e-3), (tname, r)
     checked_acts += 1
+  if name == "resnet50" and dtype == "bf16":
+    assert len(hx._bn_in_tile) == 3          # bn2a of the three 56x56 blocks
   assert checked_vars == len(store.trainable)
   assert checked_acts >= len([o for o in spec.ops if o.kind in ("conv", "dense")]) - 1
