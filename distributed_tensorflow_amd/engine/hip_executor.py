@@ -391,9 +391,9 @@ class HipExecutor:
     # scale / shift / ReLU runs there (`in_scale` of the convolution, `x_scale` of the weight
     # gradient) and the normalised tensor is never written or read - the apply sweep (one read, one
     # write of the tensor) disappears, the backward sweeps take the ReLU mask from the sign of
-    # the recomputed value.  Large tensors only: a small one has its backward statistics
-    # accumulated by the data gradient, which needs the mask bits of the apply sweep
-    # (DTF_BN_IN_TILE=0: never, 2: whatever the size).
+    # the recomputed value (and its backward statistics are not accumulated by a data gradient,
+    # which would need the mask bits of the apply sweep).  DTF_BN_IN_TILE=0: never, 2: the
+    # whole-rows tiles wherever they serve the layer, whatever the table says.
     self._bn_in_tile: Dict[str, Op] = {}        # BatchNorm name -> consumer convolution
     self._in_tile_of: Dict[str, Op] = {}        # convolution name -> BatchNorm
     self._in_tile_cfg: Dict[str, Tuple[int, int]] = {}   # convolution name -> (forward, weight-gradient) tile
@@ -403,7 +403,6 @@ class HipExecutor:
       for op in spec.ops:
         for t in op.inputs:
           users.setdefault(t, []).append(op)
-      small = int(os.environ.get("DTF_BWD_STATS_SMALL_BYTES", self.BWD_STATS_SMALL_BYTES))
       probe = torch.zeros(16, device=self.device)
       pp = probe.data_ptr()
       for b in bn_ops:
@@ -412,12 +411,11 @@ class HipExecutor:
             or b.name in self._bn_prologue or not b.attrs["relu"] or len(b.inputs) != 1
             or len(u) != 1 or u[0].kind != "conv" or b.output == spec.logits_name):
           continue
-        if in_tile != "2" and self.fused_bn_bwd_stats and acts[b.output].numel() * self.esize <= small:
-          continue
         g = geoms[u[0].name]
+        # (placeholder pointers: the table is read, nothing is launched)
         fd = autotune.apply("conv", g.fwd(pp, pp, pp, stats=pp if u[0].output in self._stats_of_conv else None,
-                                          stats_replicas=self.STATS_REPLICAS))
-        wd = autotune.apply("wgrad", g.wgrad(pp, pp, pp))
+                                          stats_replicas=self.STATS_REPLICAS), measure=False)
+        wd = autotune.apply("wgrad", g.wgrad(pp, pp, pp), measure=False)
         if in_tile == "2":               # tests: the whole-rows tiles wherever they serve the layer
           fd = next((dict(fd, cfg=c) for c in (52, 49) if native.ext().conv_rows_serves(dict(fd, cfg=c))), fd)
           wd = dict(wd, cfg=192)
@@ -664,10 +662,16 @@ class HipExecutor:
 
   def _add(self, plan, kind: str, desc: Dict, name: str, lane: int = 0):
     """plan.add with the measured tile configuration of this shape, when one is known."""
+    # a launch that normalises its input inside the tile keeps the whole-rows tile it was planned with
+    pinned = desc.get("cfg") if desc.get("in_scale") is not None or desc.get("x_scale") is not None else None
     if kind in ("conv", "wgrad"):
       desc = autotune.apply(kind, desc)
     if kind in ("conv", "wgrad") and desc.get("batch") is None:
       desc = self._in_step_choice(plan, kind, desc, lane)
+    if pinned is not None:
+      desc = dict(desc, cfg=pinned)
+      if kind == "wgrad":
+        desc.setdefault("splits", 16)      # (one split asks for the fixed summation order)
     if kind == "wgrad" and self.deterministic:
       desc = dict(desc, splits=1)
     if kind == "conv" and plan is getattr(self, "bwd_plan", None) and os.environ.get("DTF_DGRAD_LANE_MAP"):

@@ -25,7 +25,8 @@ __all__ = ["signature", "lookup", "apply", "tune", "save", "enabled", "CACHE_PAT
 
 CACHE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
 _POINTERS = ("in", "wgt", "out", "addend", "addend_mask", "bias", "stats", "stats_y",
-             "stats_mask", "x", "dy", "dw", "scale", "batch")
+             "stats_mask", "x", "dy", "dw", "scale", "batch", "in_scale", "in_shift", "x_scale",
+             "x_shift", "ws")
 _IGNORED = _POINTERS + ("cfg", "splits", "stats_replicas", "rev")
 _cache: Optional[Dict[str, Dict[str, int]]] = None
 _dirty = False
@@ -158,9 +159,10 @@ def _wgrad_candidates(desc: Dict) -> List[Tuple[int, int]]:
       for lg, g in ((1, 2), (2, 4)):
         if s >= g and not (c == 8 and g == 4) and (c + 16 * lg, -(-s // g)) not in out:
           out.extend(with_depths(c + 16 * lg, -(-s // g)))
-  # 192: the whole-gradient-per-block kernel of conv_wgrad_rows.hip (56x56x64 3x3, unit stride);
+  # 192: the whole-rows kernel of conv_wgrad_rows.hip (56x56x64 and 28x28x128 3x3, unit stride);
   # the split count is kept for the fallback tile
-  if (desc.get("TI"), desc.get("TJ"), desc.get("Cpix"), desc.get("W"), cout) == (3, 3, 64, 56, 64) \
+  if (desc.get("TI"), desc.get("TJ"), desc.get("Cpix"), desc.get("W"), cout) in ((3, 3, 64, 56, 64),
+                                                                                 (3, 3, 128, 28, 128)) \
       and desc.get("ISH", 1) == 1 and desc.get("batch") is None and out:
     out.append((192, out[0][1]))
   return out
@@ -233,11 +235,12 @@ def tune(kind: str, desc: Dict) -> Dict[str, int]:
 RETUNE = None
 
 
-def apply(kind: str, desc: Dict) -> Dict:
-  """Returns `desc` with the tuned configuration filled in (tuning it first when enabled)."""
+def apply(kind: str, desc: Dict, measure: bool = True) -> Dict:
+  """Returns `desc` with the tuned configuration filled in (tuning it first when enabled;
+  `measure=False`: from the table only - for a descriptor whose pointers are placeholders)."""
   hit = lookup(kind, desc)
-  if enabled() and (hit is None or (RETUNE is not None and RETUNE(kind, desc)
-                                    and signature(kind, desc) not in _retuned)):
+  if measure and enabled() and (hit is None or (RETUNE is not None and RETUNE(kind, desc)
+                                                and signature(kind, desc) not in _retuned)):
     hit = tune(kind, desc)
   if hit is not None:
     desc = dict(desc)

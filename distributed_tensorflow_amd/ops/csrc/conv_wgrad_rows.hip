@@ -54,43 +54,67 @@ __device__ __forceinline__ f32x4 mfma32(const bf16x8 a, const bf16x8 b, const f3
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-constexpr int WR_C = 64, WR_COUT = 64, WR_PITCH = 64;
+constexpr int WR_CO = 64;                            // output channels of a block
 
-template <int DT, int W, int TR>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(const WgradParams p, int tiles_per_block,
-                                                                 int ntiles) {
-  constexpr int C = WR_C, COUT = WR_COUT, PITCH = WR_PITCH;
-  constexpr int HROWS = TR + 2;
-  constexpr int HBYTES = HROWS * PITCH * C * 2;
+// swizzle of the 32-byte chunk index inside a pixel of C 16-bit channels (C / 16 chunks): a
+// function of the pixel index that differs for the 8 pixels one 32-lane half reads
+template <int C>
+__device__ __forceinline__ int swz_px(int row) {
+  if constexpr (C == 64) return swz64(row);
+  else return (row & 3) | (((row >> 3) & 1) << 2);
+}
+
+// C, COUT: channels of the layer.  W, TR: image width, output rows per tile (W * TR pixels, padded
+// to whole steps of 32 with zero rows of dY).  PITCH: halo pixels per halo row (a multiple of 16
+// >= W + 2: a tap's row shift keeps the swizzle).  NDI: kernel rows a block owns - 3: all of them
+// (64 x 576 gradient, 144 accumulator registers per lane), 1: row blockIdx.y (a third of the
+// gradient of a 128-channel layer; the three blocks of a tile each fetch their own TR input
+// rows).  blockIdx.z: the 64 output channels of the block.  Wave w owns input channels
+// 16 * CIBW * w .. of every tap of the block.
+template <int DT, int C, int COUT, int W, int TR, int PITCH, int NDI, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_wgrad_rows_kernel(const WgradParams p, int tiles_per_block,
+                                                                   int ntiles) {
+  constexpr int CO = WR_CO;
+  constexpr int CIBW = C / 64;                       // 16-channel blocks per wave
+  constexpr int NT = NDI * 3;                        // taps of the block
+  constexpr int PB = C * 2;                          // bytes per pixel
+  constexpr int UPP = C / 8;                         // 16-byte units per pixel
+  constexpr int HROWS = TR + NDI - 1;
+  constexpr int HBYTES = HROWS * PITCH * PB;
   constexpr int PIX = TR * W;
-  constexpr int KS = PIX / 32;                       // reduction steps of 32 pixels per tile
-  constexpr int YBYTES = PIX * COUT * 2;
+  constexpr int KS = (PIX + 31) / 32;                // reduction steps of 32 pixels per tile
+  constexpr int YBYTES = KS * 4096;                  // step tiles of [32 pixels][64 channels]
   constexpr int HROUNDS = HBYTES / 4096;             // DMA rounds: 256 threads x 16 bytes
-  static_assert(PIX % 32 == 0 && HBYTES % 4096 == 0 && W + 2 <= PITCH, "tile shape");
-  static_assert(2 * (HBYTES + YBYTES + 2 * C * 4) <= 160 * 1024, "two blocks per compute unit");
+  constexpr int TBYTES = 2 * C * 4;                  // scale / shift of an input normalised in the tile
+  static_assert(C == 64 || C == 128, "channels");
+  static_assert(HBYTES % 4096 == 0 && W + 2 <= PITCH && PITCH % 16 == 0, "tile shape");
+  static_assert(OCC * (HBYTES + YBYTES + TBYTES) <= 160 * 1024, "blocks per compute unit");
   typedef uint16_t T;
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
 
-  constexpr int TBYTES = 2 * C * 4;                   // scale / shift of an input normalised in the tile
   __shared__ __attribute__((aligned(16))) uint8_t smem[HBYTES + YBYTES + TBYTES];
   uint8_t* halo = smem;
   uint8_t* ys = smem + HBYTES;
   float* xtab = reinterpret_cast<float*>(smem + HBYTES + YBYTES);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int di0 = NDI == 3 ? 0 : (int)blockIdx.y;   // first kernel row of the block
+  const int co0 = (int)blockIdx.z * CO;
   const T* __restrict__ gx = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ gy = reinterpret_cast<const T*>(p.dy);
   const T* zero_page = reinterpret_cast<const T*>(g_zero_page_wr);
 
-  f32x4 acc[9][4];
+  f32x4 acc[NT][CIBW][4];
 #pragma unroll
-  for (int a = 0; a < 9; ++a)
+  for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < CIBW; ++w)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][w][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment geometry of this lane: 16-lane group g reads pixels 8 g + qq and 8 g + 4 + qq of a
-  // 32-pixel step, four channels (8 bytes) at channel offset 4 pp of the wave's 16
+  // 32-pixel step, four channels (8 bytes) at channel offset 4 pp of a 16-channel block
   const int g = lane >> 4, idx = lane & 15, qq = idx >> 2, pp = idx & 3;
   // dY tile rows: this thread fills 16-byte slot (tid & 7) of row (tid >> 3) of every step's tile
   const int yrow = tid >> 3;
@@ -114,23 +138,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(const WgradPara
       dma_wait_all();
       __syncthreads();
     }
-    // ---- halo tile: 16-byte position u holds chunk ((u & 7) >> 1 ^ swizzle) of halo pixel u >> 3 ----
+    // ---- halo tile: 16-byte position u holds chunk (u % UPP / 2 ^ swizzle) of halo pixel u / UPP ----
 #pragma unroll
     for (int it = 0; it < HROUNDS; ++it) {
       const int u = (it * 4 + wave) * 64 + lane;
-      const int hp = u >> 3, s16 = u & 7;
-      const int ch16 = ((((s16 >> 1) ^ swz64(hp)) << 1) | (s16 & 1));
+      const int hp = u / UPP, s16 = u % UPP;
+      const int ch16 = ((((s16 >> 1) ^ swz_px<C>(hp)) << 1) | (s16 & 1));
       const int hr = hp / PITCH, hc = hp % PITCH;
-      const int hi = r0 + hr - 1, wi = hc - 1;
+      const int hi = r0 + hr + di0 - 1, wi = hc - 1;
       const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)W;
       const T* src = ok ? gx + ((size_t)((n * p.H + hi) * W + wi) * C + ch16 * 8) : zero_page;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(halo + (it * 4 + wave) * 1024), 16, 0, 0);
     }
-    // ---- dY tile: KS step tiles of [32 pixels][64 channels] ----------------------------------------
+    // ---- dY tile: KS step tiles of [32 pixels][64 channels], zero rows past the tile's pixels ------
     const size_t pix0 = (size_t)(n * p.H + r0) * W;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const T* src = gy + ((pix0 + s * 32 + yrow) * (size_t)p.ldy + ych * 8);
+      const bool ok = PIX % 32 == 0 || s * 32 + yrow < PIX;
+      const T* src = ok ? gy + ((pix0 + s * 32 + yrow) * (size_t)p.ldy + co0 + ych * 8) : zero_page;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ys + s * 4096 + wave * 1024), 16, 0, 0);
     }
     dma_wait_all();
@@ -140,10 +165,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(const WgradPara
 #pragma unroll 2
       for (int it = 0; it < HROUNDS; ++it) {
         const int u = (it * 4 + wave) * 64 + lane;
-        const int hp = u >> 3, s16 = u & 7;
-        const int ch16 = ((((s16 >> 1) ^ swz64(hp)) << 1) | (s16 & 1));
+        const int hp = u / UPP, s16 = u % UPP;
+        const int ch16 = ((((s16 >> 1) ^ swz_px<C>(hp)) << 1) | (s16 & 1));
         const int hr = hp / PITCH, hc = hp % PITCH;
-        const int hi = r0 + hr - 1, wi = hc - 1;
+        const int hi = r0 + hr + di0 - 1, wi = hc - 1;
         if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)W) {
           u32x4* cell = reinterpret_cast<u32x4*>(halo + (size_t)u * 16);
           const u32x4 v = *cell;
@@ -162,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(const WgradPara
     }
     __syncthreads();
 
-    // ---- nine taps x KS steps out of LDS ----------------------------------------------------------
+    // ---- the block's taps x KS steps out of LDS ---------------------------------------------------
 #pragma unroll 1
     for (int s = 0; s < KS; ++s) {
       const uint8_t* yt = ys + s * 4096;
@@ -174,19 +199,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(const WgradPara
         yf[b] = tr_pair(yt + ra * 128 + (((b ^ swz64(ra)) << 5) | (pp << 3)),
                         yt + rb * 128 + (((b ^ swz64(rb)) << 5) | (pp << 3)));
       }
-      const int q0 = s * 32 + 8 * g + qq, q1 = q0 + 4;
+      // pixels past the tile (their dY rows are zero) read the tile's last pixel: finite values
+      int q0 = s * 32 + 8 * g + qq, q1 = q0 + 4;
+      if (PIX % 32 != 0) {
+        q0 = min(q0, PIX - 1);
+        q1 = min(q1, PIX - 1);
+      }
       const int rr0 = q0 / W, rr1 = q1 / W;
       const int hb0 = rr0 * PITCH + (q0 - rr0 * W), hb1 = rr1 * PITCH + (q1 - rr1 * W);
 #pragma unroll
       for (int dj = 0; dj < 3; ++dj) {
         const int h0 = hb0 + dj, h1 = hb1 + dj;
-        const uint8_t* a0 = halo + h0 * 128 + (((wave ^ swz64(h0)) << 5) | (pp << 3));
-        const uint8_t* a1 = halo + h1 * 128 + (((wave ^ swz64(h1)) << 5) | (pp << 3));
 #pragma unroll
-        for (int di = 0; di < 3; ++di) {
-          const bf16x8 xf = tr_pair(a0 + di * (PITCH * 128), a1 + di * (PITCH * 128));
+        for (int w = 0; w < CIBW; ++w) {
+          const int cib = wave * CIBW + w;
+          const uint8_t* a0 = halo + h0 * PB + (((cib ^ swz_px<C>(h0)) << 5) | (pp << 3));
+          const uint8_t* a1 = halo + h1 * PB + (((cib ^ swz_px<C>(h1)) << 5) | (pp << 3));
 #pragma unroll
-          for (int b = 0; b < 4; ++b) acc[di * 3 + dj][b] = mfma32<DT>(xf, yf[b], acc[di * 3 + dj][b]);
+          for (int di = 0; di < NDI; ++di) {
+            const bf16x8 xf = tr_pair(a0 + di * (PITCH * PB), a1 + di * (PITCH * PB));
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+              acc[di * 3 + dj][w][b] = mfma32<DT>(xf, yf[b], acc[di * 3 + dj][w][b]);
+          }
         }
       }
     }
@@ -194,35 +229,51 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(const WgradPara
   if (t0 >= t1) return;
 
   // ---- the block's gradient leaves the registers once -----------------------------------------------
+  const size_t part = ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NT * C * CO);
+  if (p.ws != nullptr) {
+    // to the workspace in register order - [wave][tap][channel block][16 outputs][lane] of four
+    // floats: every store instruction writes 1 KB in one piece; the summing launch knows the order
+    f32x4* dst = reinterpret_cast<f32x4*>(p.ws + part) + (size_t)wave * (NT * CIBW * 4 * 64) + lane;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int w = 0; w < CIBW; ++w)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dst[((a * CIBW + w) * 4 + b) * 64] = acc[a][w][b];
+    return;
+  }
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
-  for (int a = 0; a < 9; ++a)
+  for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const size_t off = (size_t)(a * C + wave * 16 + fq * 4 + r) * COUT;
-      if (p.ws != nullptr) {
-        float* row = p.ws + (size_t)blockIdx.x * (9 * C * COUT) + off;
+    for (int w = 0; w < CIBW; ++w)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) row[b * 16 + fr] = acc[a][b][r];
-      } else {
-        float* row = p.dw + off;
+      for (int r = 0; r < 4; ++r) {
+        const int krow = a * C + (wave * CIBW + w) * 16 + fq * 4 + r;       // row inside the block's slice
+        float* row = p.dw + ((size_t)di0 * 3 * C + krow) * COUT + co0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          if (p.debug_plain_store) row[b * 16 + fr] = acc[a][b][r];
-          else atomicAdd(row + b * 16 + fr, acc[a][b][r]);
+          if (p.debug_plain_store) row[b * 16 + fr] = acc[a][w][b][r];
+          else atomicAdd(row + b * 16 + fr, acc[a][w][b][r]);
         }
       }
-    }
 }
 
-// dw[i] += sum over partials g, g + GROUPS, ... of ws[part][i] for the block's slice of 1024 floats
-constexpr int RED_GROUPS = 16, RED_SLICE = 1024, WR_MAX_BLOCKS = 512;
+// dw slice (y, z) += sum over the partials g, g + G, ... of its blocks.  ws holds
+// [z][y][part][wave][tap][channel block][16 outputs][lane][4] (the accumulator registers of the
+// blocks as they were); the slice is nt * c rows x 64 columns at row `y * nt * c`, column `z * 64`
+// of the [9 C][COUT] gradient.  blockIdx = (256 accumulator registers, group, y + ny * z).
+constexpr int RED_GROUPS = 16, RED_SLICE = 1024;
 // (gridDim.y groups; one group: the slice has a single owner, which adds in a fixed order without
 // atomics - the deterministic mode)
 __global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(const float* __restrict__ ws, int nparts,
-                                                                int nfloats, float* __restrict__ dw) {
-  const int i = blockIdx.x * RED_SLICE + threadIdx.x * 4;
+                                                                int nfloats, float* __restrict__ dw, int ny,
+                                                                int cout, int nt, int c) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int i = e * 4;
   const int G = gridDim.y;
+  const int y = blockIdx.z % ny, z = blockIdx.z / ny;
+  ws += (size_t)blockIdx.z * nparts * nfloats;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   int g = blockIdx.y;
   for (; g + 3 * G < nparts; g += 4 * G) {      // four loads in flight
@@ -237,62 +288,74 @@ __global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(const float* __r
     const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)g * nfloats + i);
     s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
   }
-  if (G == 1) {
-    f32x4 d = *reinterpret_cast<const f32x4*>(dw + i);
-    d[0] += s[0]; d[1] += s[1]; d[2] += s[2]; d[3] += s[3];
-    *reinterpret_cast<f32x4*>(dw + i) = d;
-  } else {
+  // which accumulator register this was: rows 4 (lane / 16) + r of its 16-channel block, column lane % 16
+  const int cibw = c / 64;
+  const int lane = e & 63, b = (e >> 6) & 3, t = e >> 8;
+  const int w = t % cibw, a = (t / cibw) % nt, wave = t / (cibw * nt);
+  const int krow = a * c + (wave * cibw + w) * 16 + (lane >> 4) * 4;
+  float* dst = dw + ((size_t)y * (nt * c) + krow) * cout + z * WR_CO + b * 16 + (lane & 15);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(dw + i + e, s[e]);
+  for (int r = 0; r < 4; ++r) {
+    if (G == 1) dst[(size_t)r * cout] += s[r];
+    else atomicAdd(dst + (size_t)r * cout, s[r]);
   }
 }
 
-template <int W, int TR>
-bool rows_shape_ok(const WgradParams& p) {
-  return p.W == W && p.H % TR == 0;
-}
+constexpr size_t WR_WS_FLOATS = (size_t)512 * 9 * 64 * 64;     // = 768 blocks x 3 x 128 x 64
 
-template <int W, int TR>
-void launch_rows(const WgradParams& p, hipStream_t stream) {
+template <int C, int COUT, int W, int TR, int PITCH, int NDI, int OCC>
+bool launch_rows(const WgradParams& p, hipStream_t stream, bool probe) {
+  if (p.Cpix != C || p.Cout != COUT || p.W != W || p.H % TR) return false;
+  if (probe) return true;
+  const int ny = NDI == 3 ? 1 : 3, nz = COUT / WR_CO;
   const int ntiles = p.N * (p.H / TR);
-  int blocks = WR_MAX_BLOCKS;                // two blocks on each of the 256 compute units
+  int blocks = 256 * OCC / (ny * nz);        // OCC blocks on each of the 256 compute units in all
   if (blocks > ntiles) blocks = ntiles;
   const int tpb = (ntiles + blocks - 1) / blocks;
   blocks = (ntiles + tpb - 1) / tpb;
+  constexpr int NF = NDI * 3 * C * WR_CO;
+  static_assert(NF % RED_SLICE == 0, "slices");
+  if ((size_t)blocks * ny * nz * NF > WR_WS_FLOATS) throw std::logic_error("conv_wgrad_rows: workspace");
+  const dim3 grid(blocks, ny, nz);
   if (p.dt == DT_F16)
-    hipLaunchKernelGGL((conv_wgrad_rows_kernel<DT_F16, W, TR>), dim3(blocks), dim3(256), 0, stream, p, tpb, ntiles);
+    hipLaunchKernelGGL((conv_wgrad_rows_kernel<DT_F16, C, COUT, W, TR, PITCH, NDI, OCC>), grid, dim3(256), 0,
+                       stream, p, tpb, ntiles);
   else
-    hipLaunchKernelGGL((conv_wgrad_rows_kernel<DT_BF16, W, TR>), dim3(blocks), dim3(256), 0, stream, p, tpb, ntiles);
+    hipLaunchKernelGGL((conv_wgrad_rows_kernel<DT_BF16, C, COUT, W, TR, PITCH, NDI, OCC>), grid, dim3(256), 0,
+                       stream, p, tpb, ntiles);
   if (p.ws != nullptr) {
-    constexpr int NF = 9 * WR_C * WR_COUT;
-    static_assert(NF % RED_SLICE == 0, "slices");
     // splits == 1 is how the engine asks for a summation order that does not depend on timing
     const int groups = p.splits == 1 ? 1 : (blocks < RED_GROUPS ? blocks : RED_GROUPS);
-    hipLaunchKernelGGL(wgrad_rows_reduce_kernel, dim3(NF / RED_SLICE, groups), dim3(256), 0, stream, p.ws,
-                       blocks, NF, p.dw);
+    hipLaunchKernelGGL(wgrad_rows_reduce_kernel, dim3(NF / RED_SLICE, groups, ny * nz), dim3(256), 0, stream,
+                       p.ws, blocks, NF, p.dw, ny, COUT, NDI * 3, C);
   }
+  return true;
 }
 
-}  // namespace
-
-// 3x3, unit stride, padding 1, 64 -> 64 channels, 16-bit elements, one layer per launch
-bool wgrad_rows_serves(const WgradParams& p, int cfg) {
+bool rows_dispatch(const WgradParams& p, int cfg, hipStream_t stream, bool probe) {
   if (cfg != WGRAD_ROWS_CFG) return false;
   if (p.batch != nullptr || (p.dt != DT_BF16 && p.dt != DT_F16)) return false;
   if (p.TI != 3 || p.TJ != 3 || p.ISH != 1 || p.ISW != 1 || p.dh0 != -1 || p.dw0 != -1 || p.dhs != 1 ||
       p.dws != 1 || p.OH != p.H || p.OW != p.W)
     return false;
-  if (p.Cpix != WR_C || p.Ctap != WR_C || p.Creal != WR_C || p.Cpad != WR_C || p.Cout != WR_COUT ||
-      p.ldy != WR_COUT || p.TJpad != 3 || p.TJreal != 3)
+  if (p.Ctap != p.Cpix || p.Creal != p.Cpix || p.Cpad != p.Cpix || p.ldy != p.Cout || p.TJpad != 3 ||
+      p.TJreal != 3)
     return false;
-  if ((int64_t)p.N * p.H * p.W * WR_C >= (1ll << 31)) return false;
-  return rows_shape_ok<56, 4>(p);
+  if ((int64_t)p.N * p.H * p.W * p.Cpix >= (1ll << 31)) return false;
+  //                  C  COUT   W rows pitch kernel rows / block, blocks / CU
+  if (launch_rows<64, 64, 56, 4, 64, 3, 2>(p, stream, probe)) return true;      // 77 KB LDS
+  if (launch_rows<128, 128, 28, 4, 32, 1, 3>(p, stream, probe)) return true;    // 49 KB LDS
+  return false;
 }
 
-size_t wgrad_rows_workspace_floats() { return (size_t)WR_MAX_BLOCKS * 9 * WR_C * WR_COUT; }
+}  // namespace
+
+// 3x3, unit stride, padding 1, 16-bit elements, one layer per launch: 56x56x64 -> 64 and
+// 28x28x128 -> 128
+bool wgrad_rows_serves(const WgradParams& p, int cfg) { return rows_dispatch(p, cfg, nullptr, true); }
+
+size_t wgrad_rows_workspace_floats() { return WR_WS_FLOATS; }
 
 bool launch_conv_wgrad_rows(const WgradParams& p, int cfg, hipStream_t stream) {
-  if (!wgrad_rows_serves(p, cfg)) return false;
-  launch_rows<56, 4>(p, stream);
-  return true;
+  return rows_dispatch(p, cfg, stream, false);
 }

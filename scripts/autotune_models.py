@@ -3,11 +3,12 @@
 current GPU and writes the cache file used by `ops/autotune.py`.
 
     DTF_AUTOTUNE_OUT=gpurun_out/tuned_gfx950.json python scripts/autotune_models.py \
-        [--retune_rows | --retune_addend] [model:batch[:dtype] ...]
+        [--retune_rows | --retune_wgrad_rows | --retune_addend] [model:batch[:dtype] ...]
                                    (default: resnet50:256 resnet56:128 resnet50:128 resnet20:128
                                     resnet50:256:fp16)
 
---retune_rows measures again the shapes the whole-rows kernels can serve, --retune_addend the
+--retune_rows measures again the shapes the whole-rows kernels can serve (--retune_wgrad_rows: their
+weight gradients), --retune_addend the
 launches whose epilogue adds another tensor; entries of other shapes are kept.
 """
 import os
@@ -32,6 +33,9 @@ def main():
     autotune.RETUNE = lambda kind, desc: kind == "conv" and desc.get("addend") is not None
   if "--retune_rows" in sys.argv:
     autotune.RETUNE = lambda kind, desc: kind == "conv" and bool(autotune._rows_candidates(desc))
+  if "--retune_wgrad_rows" in sys.argv:
+    autotune.RETUNE = lambda kind, desc: kind == "wgrad" and any(
+        c == 192 for c, _s in autotune._wgrad_candidates(desc))
   dev = torch.device("cuda", 0)
   for job in jobs:
     name, batch, dtype = (job.split(":") + ["bf16"])[:3]

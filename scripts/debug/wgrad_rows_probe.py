@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Times the whole-rows weight-gradient kernel (cfg 192) on the 56x56x64 3x3 layer of ResNet-50:
+"""Times the whole-rows weight-gradient kernel (cfg 192) on the 56x56x64 and 28x28x128 3x3 layers of ResNet-50:
 with atomics, with plain stores (what the flush costs) and on a batch where every block has one tile
 (what a tile costs end to end).  Run under rocprofv3 --pmc for the LDS counters."""
 import os
@@ -26,18 +26,19 @@ def timeit(fn, iters=20, warm=3):
 def main():
   dev = torch.device("cuda")
   cfgs = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "192").split(",")]
-  for N in (256, 64, 37):
-    g = ConvGeom(N, 56, 56, 64, 3, 3, 64, 1, (1, 1, 1, 1))
-    x = torch.randn(N, 56, 56, 64, device=dev).to(torch.bfloat16)
-    dy = torch.randn(N, 56, 56, 64, device=dev).to(torch.bfloat16)
-    dw = torch.zeros(3, 3, 64, 64, device=dev)
+  for N, HW, C in ((256, 56, 64), (64, 56, 64), (37, 56, 64), (256, 28, 128), (64, 28, 128)):
+    g = ConvGeom(N, HW, HW, C, 3, 3, C, 1, (1, 1, 1, 1))
+    x = torch.randn(N, HW, HW, C, device=dev).to(torch.bfloat16)
+    dy = torch.randn(N, HW, HW, C, device=dev).to(torch.bfloat16)
+    dw = torch.zeros(3, 3, C, C, device=dev)
     for cfg in cfgs:
       d = g.wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), cfg=cfg)
       t = timeit(lambda: native.run_op("wgrad", d))
       ta = timeit(lambda: native.run_op("wgrad", dict(d, atomic_flush=1)))
       tp = timeit(lambda: native.run_op("wgrad", dict(d, atomic_flush=1, debug_plain_store=1)))
-      print("N=%d cfg %d: %.1f us (%.0f TFLOP/s); every block adding atomically %.1f us, plain stores "
-            "instead %.1f us" % (N, cfg, t, 2 * N * 3136 * 64 * 576 / t / 1e6, ta, tp), flush=True)
+      print("N=%d %dx%dx%d cfg %d: %.1f us (%.0f TFLOP/s); every block adding atomically %.1f us, plain "
+            "stores instead %.1f us" % (N, HW, HW, C, cfg, t, 2 * N * HW * HW * C * 9 * C / t / 1e6, ta, tp),
+            flush=True)
 
 
 if __name__ == "__main__":

@@ -1145,16 +1145,18 @@ def test_conv_whole_rows_kernel(case, cfg):
   _check_conv_cfg(case, cfg)
 
 
-@pytest.mark.parametrize("N,dtype", [(3, torch.bfloat16), (1, torch.bfloat16), (5, torch.float16)])
-def test_wgrad_whole_rows_kernel(N, dtype):
-  """conv_wgrad_rows.hip (cfg 192: a block owns the whole gradient of a 56x56x64 3x3 layer, the halo
-  tile of X and the tile of dY fetched once per four output rows) against the PyTorch fp32
-  convolution's weight gradient; on top of a gradient that is already there (it accumulates); and a
-  layer it cannot serve falls back to a tile of the general kernel."""
+@pytest.mark.parametrize("N,dtype,HW,C", [(3, torch.bfloat16, 56, 64), (1, torch.bfloat16, 56, 64),
+                                          (5, torch.float16, 56, 64), (3, torch.bfloat16, 28, 128),
+                                          (37, torch.float16, 28, 128)])
+def test_wgrad_whole_rows_kernel(N, dtype, HW, C):
+  """conv_wgrad_rows.hip (cfg 192: the halo tile of X and the tile of dY of four output rows fetched
+  once; 56x56x64: a block owns the whole gradient, 28x28x128: one kernel row for 64 output channels)
+  against the PyTorch fp32 convolution's weight gradient; on top of a gradient that is already there
+  (it accumulates); and a layer it cannot serve falls back to a tile of the general kernel."""
   native = _native()
   dev = torch.device("cuda")
-  H = W = 56
-  Cin = Cout = 64
+  H = W = HW
+  Cin = Cout = C
   gen = torch.Generator(device="cpu").manual_seed(N)
   pad = same_padding(H, 3, 1) + same_padding(W, 3, 1)
   g = ConvGeom(N, H, W, Cin, 3, 3, Cout, 1, pad)
@@ -1182,13 +1184,13 @@ def test_wgrad_whole_rows_kernel(N, dtype):
   torch.cuda.synchronize()
   err = (dw - before - 2 * wr.grad).abs().max().item()
   assert err <= 4e-3 * wr.grad.abs().max().item() + 2e-3, err
-  # 28x28x128 is not this kernel's: same cfg, served by the general kernel
-  g2 = ConvGeom(2, 28, 28, 128, 3, 3, 128, 1, same_padding(28, 3, 1) + same_padding(28, 3, 1))
-  x2 = _bf(torch.randn(2, 28, 28, 128, generator=gen)).to(dev)
-  dy2 = _bf(torch.randn(2, 28, 28, 128, generator=gen)).to(dev)
-  wr2 = torch.zeros(3, 3, 128, 128, device=dev).requires_grad_(True)
-  _ref_conv(x2.float(), wr2, 1, same_padding(28, 3, 1) + same_padding(28, 3, 1)).backward(dy2.float())
-  dw2 = torch.zeros(3, 3, 128, 128, device=dev)
+  # 14x14x256 is not this kernel's: same cfg, served by the general kernel
+  g2 = ConvGeom(2, 14, 14, 256, 3, 3, 256, 1, same_padding(14, 3, 1) + same_padding(14, 3, 1))
+  x2 = _bf(torch.randn(2, 14, 14, 256, generator=gen)).to(dev)
+  dy2 = _bf(torch.randn(2, 14, 14, 256, generator=gen)).to(dev)
+  wr2 = torch.zeros(3, 3, 256, 256, device=dev).requires_grad_(True)
+  _ref_conv(x2.float(), wr2, 1, same_padding(14, 3, 1) + same_padding(14, 3, 1)).backward(dy2.float())
+  dw2 = torch.zeros(3, 3, 256, 256, device=dev)
   d2 = g2.wgrad(x2.data_ptr(), dy2.data_ptr(), dw2.data_ptr(), cfg=192)
   assert not native.ext().wgrad_rows_serves(d2)
   native.run_op("wgrad", d2)
@@ -1283,19 +1285,19 @@ def test_whole_rows_kernels_normalise_their_input_inside_the_tile(case, cfg):
     native.run_op("conv", dict(d, cfg=30))
 
 
-@pytest.mark.parametrize("N", [3, 2])
-def test_whole_rows_weight_gradient_normalises_x_inside_the_tile(N):
+@pytest.mark.parametrize("N,HW,C", [(3, 56, 64), (2, 56, 64), (5, 28, 128)])
+def test_whole_rows_weight_gradient_normalises_x_inside_the_tile(N, HW, C):
   """conv_wgrad_rows.hip with `x_scale` / `x_shift` against the same launch on a normalised X."""
   native = _native()
   dev = torch.device("cuda")
   gen = torch.Generator(device="cpu").manual_seed(N)
-  g = ConvGeom(N, 56, 56, 64, 3, 3, 64, 1, (1, 1, 1, 1))
-  y = _bf(torch.randn(N, 56, 56, 64, generator=gen)).to(dev)
-  scale = (torch.rand(64, generator=gen) + 0.5).to(dev)
-  shift = (torch.randn(64, generator=gen) * 0.5 + 0.3).to(dev)
+  g = ConvGeom(N, HW, HW, C, 3, 3, C, 1, (1, 1, 1, 1))
+  y = _bf(torch.randn(N, HW, HW, C, generator=gen)).to(dev)
+  scale = (torch.rand(C, generator=gen) + 0.5).to(dev)
+  shift = (torch.randn(C, generator=gen) * 0.5 + 0.3).to(dev)
   a = _affine_relu(y, scale, shift)
-  dy = _bf(torch.randn(N, 56, 56, 64, generator=gen)).to(dev)
-  dw_ref = torch.zeros(3, 3, 64, 64, device=dev)
+  dy = _bf(torch.randn(N, HW, HW, C, generator=gen)).to(dev)
+  dw_ref = torch.zeros(3, 3, C, C, device=dev)
   dw = torch.zeros_like(dw_ref)
   native.run_op("wgrad", g.wgrad(a.data_ptr(), dy.data_ptr(), dw_ref.data_ptr(), cfg=192, splits=1))
   d = dict(g.wgrad(y.data_ptr(), dy.data_ptr(), dw.data_ptr(), cfg=192, splits=1),
@@ -1303,7 +1305,7 @@ def test_whole_rows_weight_gradient_normalises_x_inside_the_tile(N):
   native.run_op("wgrad", d)
   torch.cuda.synchronize()
   assert torch.equal(dw, dw_ref)               # one split: a fixed summation order in both launches
-  wr = torch.zeros(3, 3, 64, 64, device=dev).requires_grad_(True)
+  wr = torch.zeros(3, 3, C, C, device=dev).requires_grad_(True)
   _ref_conv(a.float(), wr, 1, (1, 1, 1, 1)).backward(dy.float())
   assert (dw - wr.grad).abs().max().item() <= 2e-3 * wr.grad.abs().max().item() + 1e-3
   with pytest.raises(ValueError):
