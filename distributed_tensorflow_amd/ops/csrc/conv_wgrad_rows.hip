@@ -98,7 +98,9 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_rows_kernel(const WgradPa
   uint8_t* ys = smem + HBYTES;
   float* xtab = reinterpret_cast<float*>(smem + HBYTES + YBYTES);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // (the 128-channel tile has 168 registers per lane: its wave index lives in a scalar register)
+  const int wave = C == 128 ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
   const int di0 = NDI == 3 ? 0 : (int)blockIdx.y;   // first kernel row of the block
   const int co0 = (int)blockIdx.z * CO;
   const T* __restrict__ gx = reinterpret_cast<const T*>(p.x);
