@@ -163,21 +163,25 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_rows_kernel(const WgradPa
     dma_wait_all();
     if (p.x_scale != nullptr) {
       // BatchNorm + ReLU of the layer in front on the positions this thread fetched itself
-      // (out-of-image pixels stay zero), as the forward launch did in its halo tile
+      // (out-of-image pixels stay zero), as the forward launch did in its halo tile.  A round moves
+      // the thread 32 (64-channel pixels) or 16 pixels on, which leaves the swizzle bits alone: the
+      // thread's eight channels - its scale and shift - are the same in every round.
+      static_assert((4 * 64 / UPP) % 16 == 0, "a round keeps the swizzle of a thread's position");
+      const int u0 = wave * 64 + lane;
+      const int ch0 = (((((u0 % UPP) >> 1) ^ swz_px<C>(u0 / UPP)) << 1) | (u0 & 1));
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(xtab + ch0 * 8);
+      const f32x4 s1 = *reinterpret_cast<const f32x4*>(xtab + ch0 * 8 + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(xtab + C + ch0 * 8);
+      const f32x4 h1 = *reinterpret_cast<const f32x4*>(xtab + C + ch0 * 8 + 4);
 #pragma unroll 2
       for (int it = 0; it < HROUNDS; ++it) {
         const int u = (it * 4 + wave) * 64 + lane;
-        const int hp = u / UPP, s16 = u % UPP;
-        const int ch16 = ((((s16 >> 1) ^ swz_px<C>(hp)) << 1) | (s16 & 1));
+        const int hp = u / UPP;
         const int hr = hp / PITCH, hc = hp % PITCH;
         const int hi = r0 + hr + di0 - 1, wi = hc - 1;
         if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)W) {
           u32x4* cell = reinterpret_cast<u32x4*>(halo + (size_t)u * 16);
           const u32x4 v = *cell;
-          const f32x4 s0 = *reinterpret_cast<const f32x4*>(xtab + ch16 * 8);
-          const f32x4 s1 = *reinterpret_cast<const f32x4*>(xtab + ch16 * 8 + 4);
-          const f32x4 h0 = *reinterpret_cast<const f32x4*>(xtab + C + ch16 * 8);
-          const f32x4 h1 = *reinterpret_cast<const f32x4*>(xtab + C + ch16 * 8 + 4);
           u32x4 o;
           o.x = pack2<DT>(fmaxf(lo16<DT>(v.x) * s0[0] + h0[0], 0.f), fmaxf(hi16<DT>(v.x) * s0[1] + h0[1], 0.f));
           o.y = pack2<DT>(fmaxf(lo16<DT>(v.y) * s0[2] + h0[2], 0.f), fmaxf(hi16<DT>(v.y) * s0[3] + h0[3], 0.f));

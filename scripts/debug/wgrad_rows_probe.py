@@ -36,9 +36,13 @@ def main():
       t = timeit(lambda: native.run_op("wgrad", d))
       ta = timeit(lambda: native.run_op("wgrad", dict(d, atomic_flush=1)))
       tp = timeit(lambda: native.run_op("wgrad", dict(d, atomic_flush=1, debug_plain_store=1)))
+      tn = float("nan")
+      if cfg == 192:        # BatchNorm + ReLU of X inside the tile
+        sc, sh = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+        tn = timeit(lambda: native.run_op("wgrad", dict(d, x_scale=sc.data_ptr(), x_shift=sh.data_ptr())))
       print("N=%d %dx%dx%d cfg %d: %.1f us (%.0f TFLOP/s); every block adding atomically %.1f us, plain "
-            "stores instead %.1f us" % (N, HW, HW, C, cfg, t, 2 * N * HW * HW * C * 9 * C / t / 1e6, ta, tp),
-            flush=True)
+            "stores instead %.1f us; normalising X in the tile %.1f us"
+            % (N, HW, HW, C, cfg, t, 2 * N * HW * HW * C * 9 * C / t / 1e6, ta, tp, tn), flush=True)
 
 
 if __name__ == "__main__":
