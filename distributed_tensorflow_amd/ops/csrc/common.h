@@ -32,8 +32,14 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(bf16_t, h);
 }
 
+// Two values in one v_cvt_pk_bf16_f32 (converted one by one they cost two conversions, a shift and
+// an or).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
 __device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
@@ -168,8 +174,12 @@ __device__ __forceinline__ float hi16(uint32_t w) {
 
 template <int DT>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  if constexpr (DT == DT_F16) return (uint32_t)f2h(lo) | ((uint32_t)f2h(hi) << 16);
-  else return pack2bf(lo, hi);
+  if constexpr (DT == DT_F16) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));      // v_cvt_pk_f16_f32
+  } else {
+    return pack2bf(lo, hi);
+  }
 }
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
