@@ -6,23 +6,25 @@
 // nine taps of a 3x3 layer fetch the same input pixels nine times and every k-tile fetches dY
 // again: 1.8 KB through L2 per pixel where the tensors hold 256 bytes (56x56x64: 1.4 GB per
 // launch - the layer runs at the rate of the L2, 146 us for 59 GFLOP).  Here a block owns the
-// WHOLE gradient of the layer (64 x 576 fp32 = 144 accumulator registers per lane) and walks over
-// tiles of TR output rows: the halo tile [(TR + 2) rows][W + 2 pixels][64 channels] of X and the
+// WHOLE gradient of 64 input x 64 output channels (64 x 576 fp32 = 144 accumulator registers per
+// lane; a layer of 128 x 128 channels is four such slices, blockIdx.y / z) and walks over tiles
+// of TR output rows: the halo tile [(TR + 2) rows][W + 2 pixels][64 channels] of X and the
 // [TR * W pixels][64] tile of dY are fetched once by direct-to-LDS loads, all nine taps are
 // multiplied out of LDS, and the accumulators leave the registers once, at the end of the
 // block's tile range.  512 blocks adding 147 KB each with fp32 atomics take 44 us (atomics of
 // different XCDs meet at the memory side, about 13 cache-line operations per clock whatever the
 // address pattern - more than the multiplication itself), so the blocks store their partial
-// gradients to a workspace with plain stores and a second launch sums them: 16 groups of
-// partials per 4 KB slice, the group sums added to the HWIO gradient with 2.4 MB of atomics.
+// gradients to a workspace with plain stores (in register order: 1 KB per store instruction)
+// and a second launch sums them: 16 groups of partials per 4 KB piece, the group sums added to
+// the HWIO gradient with 2.4 MB of atomics.
 //
 // Both MFMA operands need the reduction index (the pixel) contiguous per lane while both tensors
 // are pixel-major: fragments are read with ds_read_b64_tr_b16 (conv_wgrad.hip).  Halo rows are
-// 64 pixels apart in LDS, so a tap's row shift is an immediate offset of the read and only its
+// PITCH pixels apart in LDS, so a tap's row shift is an immediate offset of the read and only its
 // column shift (0, 1, 2 pixels) needs address arithmetic; the 32-byte channel chunks of a pixel
 // are XOR-swizzled with bits 1 and 3 of the pixel index, which keeps the 8 pixels one 32-lane
 // half reads (p .. p + 3, p + 8 .. p + 11) in 8 distinct bank groups for every shift.
-// Wave w owns input channels 16 w .. 16 w + 15 of all nine taps and all output channels.
+// Wave w owns input channels 16 w .. 16 w + 15 of the slice, all nine taps and all 64 output channels.
 #include <stdexcept>
 
 #include "common.h"
@@ -54,41 +56,26 @@ __device__ __forceinline__ f32x4 mfma32(const bf16x8 a, const bf16x8 b, const f3
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-constexpr int WR_CO = 64;                            // output channels of a block
+constexpr int WR_C = 64, WR_CO = 64;                // input / output channels of a block's slice
 
-// swizzle of the 32-byte chunk index inside a pixel of C 16-bit channels (C / 16 chunks): a
-// function of the pixel index that differs for the 8 pixels one 32-lane half reads
-template <int C>
-__device__ __forceinline__ int swz_px(int row) {
-  if constexpr (C == 64) return swz64(row);
-  else return (row & 3) | (((row >> 3) & 1) << 2);
-}
-
-// C, COUT: channels of the layer.  W, TR: image width, output rows per tile (W * TR pixels, padded
-// to whole steps of 32 with zero rows of dY).  PITCH: halo pixels per halo row (a multiple of 16
-// >= W + 2: a tap's row shift keeps the swizzle).  NDI: kernel rows a block owns - 3: all of them
-// (64 x 576 gradient, 144 accumulator registers per lane), 1: row blockIdx.y (a third of the
-// gradient of a 128-channel layer; the three blocks of a tile each fetch their own TR input
-// rows).  blockIdx.z: the 64 output channels of the block.  Wave w owns input channels
-// 16 * CIBW * w .. of every tap of the block.
-template <int DT, int C, int COUT, int W, int TR, int PITCH, int NDI, int OCC>
-__global__ __launch_bounds__(256, OCC) void conv_wgrad_rows_kernel(const WgradParams p, int tiles_per_block,
-                                                                   int ntiles) {
-  constexpr int CO = WR_CO;
-  constexpr int CIBW = C / 64;                       // 16-channel blocks per wave
-  constexpr int NT = NDI * 3;                        // taps of the block
-  constexpr int PB = C * 2;                          // bytes per pixel
-  constexpr int UPP = C / 8;                         // 16-byte units per pixel
-  constexpr int HROWS = TR + NDI - 1;
+// CTOT, COUT: channels of the layer (multiples of 64).  W, TR: image width, output rows per tile
+// (W * TR pixels, padded to whole steps of 32 with zero rows of dY).  PITCH: halo pixels per halo
+// row (a multiple of 16 >= W + 2: a tap's row shift keeps the swizzle).  blockIdx.y / z: the 64
+// input / output channels of the block.
+template <int DT, int CTOT, int COUT, int W, int TR, int PITCH>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(const WgradParams p, int tiles_per_block,
+                                                                 int ntiles) {
+  constexpr int C = WR_C, CO = WR_CO;
+  constexpr int PB = C * 2;                          // bytes per halo pixel
+  constexpr int HROWS = TR + 2;
   constexpr int HBYTES = HROWS * PITCH * PB;
   constexpr int PIX = TR * W;
   constexpr int KS = (PIX + 31) / 32;                // reduction steps of 32 pixels per tile
   constexpr int YBYTES = KS * 4096;                  // step tiles of [32 pixels][64 channels]
   constexpr int HROUNDS = HBYTES / 4096;             // DMA rounds: 256 threads x 16 bytes
   constexpr int TBYTES = 2 * C * 4;                  // scale / shift of an input normalised in the tile
-  static_assert(C == 64 || C == 128, "channels");
   static_assert(HBYTES % 4096 == 0 && W + 2 <= PITCH && PITCH % 16 == 0, "tile shape");
-  static_assert(OCC * (HBYTES + YBYTES + TBYTES) <= 160 * 1024, "blocks per compute unit");
+  static_assert(2 * (HBYTES + YBYTES + TBYTES) <= 160 * 1024, "two blocks per compute unit");
   typedef uint16_t T;
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -98,22 +85,17 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_rows_kernel(const WgradPa
   uint8_t* ys = smem + HBYTES;
   float* xtab = reinterpret_cast<float*>(smem + HBYTES + YBYTES);
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  // (the 128-channel tile has 168 registers per lane: its wave index lives in a scalar register)
-  const int wave = C == 128 ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
-  const int di0 = NDI == 3 ? 0 : (int)blockIdx.y;   // first kernel row of the block
-  const int co0 = (int)blockIdx.z * CO;
-  const T* __restrict__ gx = reinterpret_cast<const T*>(p.x);
-  const T* __restrict__ gy = reinterpret_cast<const T*>(p.dy);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ci0 = (int)blockIdx.y * C, co0 = (int)blockIdx.z * CO;
+  const T* __restrict__ gx = reinterpret_cast<const T*>(p.x) + ci0;
+  const T* __restrict__ gy = reinterpret_cast<const T*>(p.dy) + co0;
   const T* zero_page = reinterpret_cast<const T*>(g_zero_page_wr);
 
-  f32x4 acc[NT][CIBW][4];
+  f32x4 acc[9][4];
 #pragma unroll
-  for (int a = 0; a < NT; ++a)
+  for (int a = 0; a < 9; ++a)
 #pragma unroll
-    for (int w = 0; w < CIBW; ++w)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][w][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment geometry of this lane: 16-lane group g reads pixels 8 g + qq and 8 g + 4 + qq of a
   // 32-pixel step, four channels (8 bytes) at channel offset 4 pp of a 16-channel block
@@ -124,8 +106,8 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_rows_kernel(const WgradPa
 
   if (p.x_scale != nullptr) {                        // the forward launch normalised X inside its tile
     if (tid < C) {
-      xtab[tid] = p.x_scale[tid];
-      xtab[C + tid] = p.x_shift[tid];
+      xtab[tid] = p.x_scale[ci0 + tid];
+      xtab[C + tid] = p.x_shift[ci0 + tid];
     }
     dma_wait_all();
     __syncthreads();
@@ -140,16 +122,16 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_rows_kernel(const WgradPa
       dma_wait_all();
       __syncthreads();
     }
-    // ---- halo tile: 16-byte position u holds chunk (u % UPP / 2 ^ swizzle) of halo pixel u / UPP ----
+    // ---- halo tile: 16-byte position u holds chunk (u % 8 / 2 ^ swizzle) of halo pixel u / 8 -------
 #pragma unroll
     for (int it = 0; it < HROUNDS; ++it) {
       const int u = (it * 4 + wave) * 64 + lane;
-      const int hp = u / UPP, s16 = u % UPP;
-      const int ch16 = ((((s16 >> 1) ^ swz_px<C>(hp)) << 1) | (s16 & 1));
+      const int hp = u >> 3, s16 = u & 7;
+      const int ch16 = ((((s16 >> 1) ^ swz64(hp)) << 1) | (s16 & 1));
       const int hr = hp / PITCH, hc = hp % PITCH;
-      const int hi = r0 + hr + di0 - 1, wi = hc - 1;
+      const int hi = r0 + hr - 1, wi = hc - 1;
       const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)W;
-      const T* src = ok ? gx + ((size_t)((n * p.H + hi) * W + wi) * C + ch16 * 8) : zero_page;
+      const T* src = ok ? gx + ((size_t)((n * p.H + hi) * W + wi) * CTOT + ch16 * 8) : zero_page;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(halo + (it * 4 + wave) * 1024), 16, 0, 0);
     }
     // ---- dY tile: KS step tiles of [32 pixels][64 channels], zero rows past the tile's pixels ------
@@ -157,18 +139,17 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_rows_kernel(const WgradPa
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const bool ok = PIX % 32 == 0 || s * 32 + yrow < PIX;
-      const T* src = ok ? gy + ((pix0 + s * 32 + yrow) * (size_t)p.ldy + co0 + ych * 8) : zero_page;
+      const T* src = ok ? gy + ((pix0 + s * 32 + yrow) * (size_t)p.ldy + ych * 8) : zero_page;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ys + s * 4096 + wave * 1024), 16, 0, 0);
     }
     dma_wait_all();
     if (p.x_scale != nullptr) {
       // BatchNorm + ReLU of the layer in front on the positions this thread fetched itself
       // (out-of-image pixels stay zero), as the forward launch did in its halo tile.  A round moves
-      // the thread 32 (64-channel pixels) or 16 pixels on, which leaves the swizzle bits alone: the
-      // thread's eight channels - its scale and shift - are the same in every round.
-      static_assert((4 * 64 / UPP) % 16 == 0, "a round keeps the swizzle of a thread's position");
+      // the thread 32 pixels on, which leaves the swizzle bits alone: the thread's eight channels
+      // - its scale and shift - are the same in every round.
       const int u0 = wave * 64 + lane;
-      const int ch0 = (((((u0 % UPP) >> 1) ^ swz_px<C>(u0 / UPP)) << 1) | (u0 & 1));
+      const int ch0 = (((((u0 & 7) >> 1) ^ swz64(u0 >> 3)) << 1) | (u0 & 1));
       const f32x4 s0 = *reinterpret_cast<const f32x4*>(xtab + ch0 * 8);
       const f32x4 s1 = *reinterpret_cast<const f32x4*>(xtab + ch0 * 8 + 4);
       const f32x4 h0 = *reinterpret_cast<const f32x4*>(xtab + C + ch0 * 8);
@@ -176,9 +157,9 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_rows_kernel(const WgradPa
 #pragma unroll 2
       for (int it = 0; it < HROUNDS; ++it) {
         const int u = (it * 4 + wave) * 64 + lane;
-        const int hp = u / UPP;
+        const int hp = u >> 3;
         const int hr = hp / PITCH, hc = hp % PITCH;
-        const int hi = r0 + hr + di0 - 1, wi = hc - 1;
+        const int hi = r0 + hr - 1, wi = hc - 1;
         if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)W) {
           u32x4* cell = reinterpret_cast<u32x4*>(halo + (size_t)u * 16);
           const u32x4 v = *cell;
@@ -193,7 +174,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_rows_kernel(const WgradPa
     }
     __syncthreads();
 
-    // ---- the block's taps x KS steps out of LDS ---------------------------------------------------
+    // ---- 9 taps x KS steps out of LDS -----------------------------------------------------------------
 #pragma unroll 1
     for (int s = 0; s < KS; ++s) {
       const uint8_t* yt = ys + s * 4096;
@@ -216,18 +197,13 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_rows_kernel(const WgradPa
 #pragma unroll
       for (int dj = 0; dj < 3; ++dj) {
         const int h0 = hb0 + dj, h1 = hb1 + dj;
+        const uint8_t* a0 = halo + h0 * PB + (((wave ^ swz64(h0)) << 5) | (pp << 3));
+        const uint8_t* a1 = halo + h1 * PB + (((wave ^ swz64(h1)) << 5) | (pp << 3));
 #pragma unroll
-        for (int w = 0; w < CIBW; ++w) {
-          const int cib = wave * CIBW + w;
-          const uint8_t* a0 = halo + h0 * PB + (((cib ^ swz_px<C>(h0)) << 5) | (pp << 3));
-          const uint8_t* a1 = halo + h1 * PB + (((cib ^ swz_px<C>(h1)) << 5) | (pp << 3));
+        for (int di = 0; di < 3; ++di) {
+          const bf16x8 xf = tr_pair(a0 + di * (PITCH * PB), a1 + di * (PITCH * PB));
 #pragma unroll
-          for (int di = 0; di < NDI; ++di) {
-            const bf16x8 xf = tr_pair(a0 + di * (PITCH * PB), a1 + di * (PITCH * PB));
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-              acc[di * 3 + dj][w][b] = mfma32<DT>(xf, yf[b], acc[di * 3 + dj][w][b]);
-          }
+          for (int b = 0; b < 4; ++b) acc[di * 3 + dj][b] = mfma32<DT>(xf, yf[b], acc[di * 3 + dj][b]);
         }
       }
     }
@@ -235,71 +211,66 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_rows_kernel(const WgradPa
   if (t0 >= t1) return;
 
   // ---- the block's gradient leaves the registers once -----------------------------------------------
-  const size_t part = ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NT * C * CO);
   if (p.ws != nullptr) {
-    // to the workspace in register order - [wave][tap][channel block][16 outputs][lane] of four
-    // floats: every store instruction writes 1 KB in one piece; the summing launch knows the order
-    f32x4* dst = reinterpret_cast<f32x4*>(p.ws + part) + (size_t)wave * (NT * CIBW * 4 * 64) + lane;
+    // to the workspace in register order - [wave][tap][16 outputs][lane] of four floats: every store
+    // instruction writes 1 KB in one piece; the summing launch knows the order
+    const size_t part = ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (9 * C * CO);
+    f32x4* dst = reinterpret_cast<f32x4*>(p.ws + part) + (size_t)wave * (9 * 4 * 64) + lane;
 #pragma unroll
-    for (int a = 0; a < NT; ++a)
+    for (int a = 0; a < 9; ++a)
 #pragma unroll
-      for (int w = 0; w < CIBW; ++w)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) dst[((a * CIBW + w) * 4 + b) * 64] = acc[a][w][b];
+      for (int b = 0; b < 4; ++b) dst[(a * 4 + b) * 64] = acc[a][b];
     return;
   }
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
-  for (int a = 0; a < NT; ++a)
+  for (int a = 0; a < 9; ++a)
 #pragma unroll
-    for (int w = 0; w < CIBW; ++w)
+    for (int r = 0; r < 4; ++r) {
+      float* row = p.dw + ((size_t)a * CTOT + ci0 + wave * 16 + fq * 4 + r) * COUT + co0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int krow = a * C + (wave * CIBW + w) * 16 + fq * 4 + r;       // row inside the block's slice
-        float* row = p.dw + ((size_t)di0 * 3 * C + krow) * COUT + co0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          if (p.debug_plain_store) row[b * 16 + fr] = acc[a][w][b][r];
-          else atomicAdd(row + b * 16 + fr, acc[a][w][b][r]);
-        }
+      for (int b = 0; b < 4; ++b) {
+        if (p.debug_plain_store) row[b * 16 + fr] = acc[a][b][r];
+        else atomicAdd(row + b * 16 + fr, acc[a][b][r]);
       }
+    }
 }
 
 // dw slice (y, z) += sum over the partials g, g + G, ... of its blocks.  ws holds
-// [z][y][part][wave][tap][channel block][16 outputs][lane][4] (the accumulator registers of the
-// blocks as they were); the slice is nt * c rows x 64 columns at row `y * nt * c`, column `z * 64`
-// of the [9 C][COUT] gradient.  blockIdx = (256 accumulator registers, group, y + ny * z).
+// [z][y][part][wave][tap][16 outputs][lane][4] (the accumulator registers of the blocks as they
+// were); the slice is input channels 64 y .., output channels 64 z .. of the [9][ctot][cout]
+// gradient.  blockIdx = (256 accumulator registers, group, y + ny * z).
 constexpr int RED_GROUPS = 16, RED_SLICE = 1024;
+constexpr int WR_NF = 9 * WR_C * WR_CO;              // floats of a slice
 // (gridDim.y groups; one group: the slice has a single owner, which adds in a fixed order without
 // atomics - the deterministic mode)
 __global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(const float* __restrict__ ws, int nparts,
-                                                                int nfloats, float* __restrict__ dw, int ny,
-                                                                int cout, int nt, int c) {
+                                                                float* __restrict__ dw, int ny, int ctot,
+                                                                int cout) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   const int i = e * 4;
   const int G = gridDim.y;
   const int y = blockIdx.z % ny, z = blockIdx.z / ny;
-  ws += (size_t)blockIdx.z * nparts * nfloats;
+  ws += (size_t)blockIdx.z * nparts * WR_NF;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   int g = blockIdx.y;
   for (; g + 3 * G < nparts; g += 4 * G) {      // four loads in flight
     f32x4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      v[u] = *reinterpret_cast<const f32x4*>(ws + (size_t)(g + u * G) * nfloats + i);
+      v[u] = *reinterpret_cast<const f32x4*>(ws + (size_t)(g + u * G) * WR_NF + i);
 #pragma unroll
     for (int u = 0; u < 4; ++u) { s[0] += v[u][0]; s[1] += v[u][1]; s[2] += v[u][2]; s[3] += v[u][3]; }
   }
   for (; g < nparts; g += G) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)g * nfloats + i);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)g * WR_NF + i);
     s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
   }
-  // which accumulator register this was: rows 4 (lane / 16) + r of its 16-channel block, column lane % 16
-  const int cibw = c / 64;
+  // which accumulator register this was: rows 4 (lane / 16) + r of its wave's 16 channels, column lane % 16
   const int lane = e & 63, b = (e >> 6) & 3, t = e >> 8;
-  const int w = t % cibw, a = (t / cibw) % nt, wave = t / (cibw * nt);
-  const int krow = a * c + (wave * cibw + w) * 16 + (lane >> 4) * 4;
-  float* dst = dw + ((size_t)y * (nt * c) + krow) * cout + z * WR_CO + b * 16 + (lane & 15);
+  const int a = t % 9, wave = t / 9;
+  const int krow = a * ctot + y * WR_C + wave * 16 + (lane >> 4) * 4;
+  float* dst = dw + (size_t)krow * cout + z * WR_CO + b * 16 + (lane & 15);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if (G == 1) dst[(size_t)r * cout] += s[r];
@@ -307,33 +278,32 @@ __global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(const float* __r
   }
 }
 
-constexpr size_t WR_WS_FLOATS = (size_t)512 * 9 * 64 * 64;     // = 768 blocks x 3 x 128 x 64
+constexpr int WR_MAX_BLOCKS = 512;                   // two on each of the 256 compute units
+constexpr size_t WR_WS_FLOATS = (size_t)WR_MAX_BLOCKS * WR_NF;
 
-template <int C, int COUT, int W, int TR, int PITCH, int NDI, int OCC>
+template <int CTOT, int COUT, int W, int TR, int PITCH>
 bool launch_rows(const WgradParams& p, hipStream_t stream, bool probe) {
-  if (p.Cpix != C || p.Cout != COUT || p.W != W || p.H % TR) return false;
+  if (p.Cpix != CTOT || p.Cout != COUT || p.W != W || p.H % TR) return false;
   if (probe) return true;
-  const int ny = NDI == 3 ? 1 : 3, nz = COUT / WR_CO;
+  constexpr int ny = CTOT / WR_C, nz = COUT / WR_CO;
   const int ntiles = p.N * (p.H / TR);
-  int blocks = 256 * OCC / (ny * nz);        // OCC blocks on each of the 256 compute units in all
+  int blocks = WR_MAX_BLOCKS / (ny * nz);
   if (blocks > ntiles) blocks = ntiles;
   const int tpb = (ntiles + blocks - 1) / blocks;
   blocks = (ntiles + tpb - 1) / tpb;
-  constexpr int NF = NDI * 3 * C * WR_CO;
-  static_assert(NF % RED_SLICE == 0, "slices");
-  if ((size_t)blocks * ny * nz * NF > WR_WS_FLOATS) throw std::logic_error("conv_wgrad_rows: workspace");
+  static_assert(WR_NF % RED_SLICE == 0, "pieces");
   const dim3 grid(blocks, ny, nz);
   if (p.dt == DT_F16)
-    hipLaunchKernelGGL((conv_wgrad_rows_kernel<DT_F16, C, COUT, W, TR, PITCH, NDI, OCC>), grid, dim3(256), 0,
-                       stream, p, tpb, ntiles);
+    hipLaunchKernelGGL((conv_wgrad_rows_kernel<DT_F16, CTOT, COUT, W, TR, PITCH>), grid, dim3(256), 0, stream, p,
+                       tpb, ntiles);
   else
-    hipLaunchKernelGGL((conv_wgrad_rows_kernel<DT_BF16, C, COUT, W, TR, PITCH, NDI, OCC>), grid, dim3(256), 0,
-                       stream, p, tpb, ntiles);
+    hipLaunchKernelGGL((conv_wgrad_rows_kernel<DT_BF16, CTOT, COUT, W, TR, PITCH>), grid, dim3(256), 0, stream, p,
+                       tpb, ntiles);
   if (p.ws != nullptr) {
     // splits == 1 is how the engine asks for a summation order that does not depend on timing
     const int groups = p.splits == 1 ? 1 : (blocks < RED_GROUPS ? blocks : RED_GROUPS);
-    hipLaunchKernelGGL(wgrad_rows_reduce_kernel, dim3(NF / RED_SLICE, groups, ny * nz), dim3(256), 0, stream,
-                       p.ws, blocks, NF, p.dw, ny, COUT, NDI * 3, C);
+    hipLaunchKernelGGL(wgrad_rows_reduce_kernel, dim3(WR_NF / RED_SLICE, groups, ny * nz), dim3(256), 0, stream,
+                       p.ws, blocks, p.dw, ny, CTOT, COUT);
   }
   return true;
 }
@@ -348,9 +318,9 @@ bool rows_dispatch(const WgradParams& p, int cfg, hipStream_t stream, bool probe
       p.TJreal != 3)
     return false;
   if ((int64_t)p.N * p.H * p.W * p.Cpix >= (1ll << 31)) return false;
-  //                  C  COUT   W rows pitch kernel rows / block, blocks / CU
-  if (launch_rows<64, 64, 56, 4, 64, 3, 2>(p, stream, probe)) return true;      // 77 KB LDS
-  if (launch_rows<128, 128, 28, 4, 32, 1, 3>(p, stream, probe)) return true;    // 49 KB LDS
+  //           channels in, out   W rows pitch
+  if (launch_rows<64, 64, 56, 4, 64>(p, stream, probe)) return true;        // 77 KB LDS: 224 pixels a tile
+  if (launch_rows<128, 128, 28, 7, 32>(p, stream, probe)) return true;      // 65 KB LDS: 196 pixels, 7 steps
   return false;
 }
 

@@ -1150,7 +1150,7 @@ def test_conv_whole_rows_kernel(case, cfg):
                                           (37, torch.float16, 28, 128)])
 def test_wgrad_whole_rows_kernel(N, dtype, HW, C):
   """conv_wgrad_rows.hip (cfg 192: the halo tile of X and the tile of dY of four output rows fetched
-  once; 56x56x64: a block owns the whole gradient, 28x28x128: one kernel row for 64 output channels)
+  once; a block owns the whole gradient of 64 input x 64 output channels: all of 56x56x64, a quarter of 28x28x128)
   against the PyTorch fp32 convolution's weight gradient; on top of a gradient that is already there
   (it accumulates); and a layer it cannot serve falls back to a tile of the general kernel."""
   native = _native()
