@@ -24,6 +24,26 @@ def test_signature_ignores_addresses_and_choices():
   assert autotune.signature("conv", d1) != autotune.signature("conv", d2)
 
 
+def test_placeholder_descriptors_are_never_measured(monkeypatch):
+  """The planner asks which tile the table holds for a layer with descriptors whose pointers are
+  placeholders (`measure=False`): even with tuning on and the shape missing or marked for another
+  measurement nothing may be launched; the pointers of an input normalised inside the tile are not
+  part of the signature."""
+  g = ConvGeom(7, 56, 56, 64, 3, 3, 64, 1, (1, 1, 1, 1))
+  monkeypatch.setenv("DTF_AUTOTUNE", "1")
+  monkeypatch.setattr(autotune, "RETUNE", lambda kind, desc: True)
+
+  def boom(kind, desc):
+    raise AssertionError("a placeholder descriptor was launched")
+  monkeypatch.setattr(autotune, "tune", boom)
+  d = g.wgrad(16, 16, 16)
+  assert autotune.apply("wgrad", d, measure=False) == d           # batch 7 is in no table
+  f = g.fwd(16, 16, 16)
+  assert autotune.apply("conv", f, measure=False) == f
+  assert autotune.signature("conv", f) == autotune.signature("conv", dict(f, in_scale=123, in_shift=456))
+  assert autotune.signature("wgrad", d) == autotune.signature("wgrad", dict(d, x_scale=123, x_shift=456, ws=789))
+
+
 def test_apply_uses_cache_and_falls_back(tmp_path, monkeypatch):
   g = _geom()
   d = g.wgrad(1, 2, 3)
