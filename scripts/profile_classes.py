@@ -53,6 +53,9 @@ def main():
   for label, _ in CLASSES:
     print("| %s | %d | %.2f | %.2f | %.2f |" % (label, round(calls[label]), fetch[label], write[label], ms[label]))
   print("| **total** | | **%.1f** | **%.1f** | %.1f |" % (sum(fetch.values()), sum(write.values()), sum(ms.values())))
+  once = "buffer fills at planning time (torch)"      # once per process, here spread over the profiled steps
+  print("| **total of a steady-state step** (without the planning-time fills) | | **%.1f** | **%.1f** | %.1f |"
+        % (sum(fetch.values()) - fetch[once], sum(write.values()) - write[once], sum(ms.values()) - ms[once]))
 
 
 if __name__ == "__main__":
