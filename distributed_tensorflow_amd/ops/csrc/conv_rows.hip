@@ -243,6 +243,7 @@ void conv_rows_kernel(const ConvParams p) {
 
   // ---- 4. K loop: taps outside, stages of SPS channel chunks inside --------------------------------
   int read_stage = 0, issue_stage = STAGES - 1, sidx = 0;
+  const int fqoff = ((fq >> 1) << 8) + ((fq & 1) << 7);    // the lane's chunk inside a group of eight pixels
   for (int ti = 0; ti < 3; ++ti) {
     for (int tj = 0; tj < 3; ++tj) {
       const int trow = p.dh0 + ti * p.dhs - org_h, tcol = p.dw0 + tj * p.dws - org_w;
@@ -250,8 +251,9 @@ void conv_rows_kernel(const ConvParams p) {
       int hbase[MR];                   // the lane's pixel and its chunk fq of the tap's first K-step
 #pragma unroll
       for (int mr = 0; mr < MR; ++mr) {
+        // (((hp >> 3) * (CPP / 2) + (fq >> 1)) << 8) + ((fq & 1) << 7) + ((hp & 7) << 4), in three operations
         const int hp = hp0[mr] + shift;
-        hbase[mr] = ((((hp >> 3) * (CPP / 2)) + (fq >> 1)) << 8) + ((fq & 1) << 7) + ((hp & 7) << 4);
+        hbase[mr] = (hp >> 3) * (CPP * 128 - 128) + ((hp << 4) + fqoff);
       }
 #pragma unroll
       for (int gs = 0; gs < GPT; ++gs, ++sidx) {
