@@ -66,6 +66,13 @@ __device__ __forceinline__ void rows_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// At most N of this wave's DMA loads still in flight and its LDS reads retired, then the block
+// meets - one statement, so that the scheduler puts nothing between the waits and the barrier.
+template <int N>
+__device__ __forceinline__ void rows_wait_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 // STAGES: depth of the weight ring; SPS: K-steps (of 32) per stage, i.e. per barrier.
 // OCC: waves per SIMD the register allocation has to allow (blocks per CU the LDS admits).
 template <int DT, int C, int W, int TR, int BN, int WAVES_M, int WAVES_N, int STAGES, int SPS,
@@ -253,19 +260,18 @@ void conv_rows_kernel(const ConvParams p) {
       for (int mr = 0; mr < MR; ++mr) {
         // (((hp >> 3) * (CPP / 2) + (fq >> 1)) << 8) + ((fq & 1) << 7) + ((hp & 7) << 4), in three operations
         const int hp = hp0[mr] + shift;
-        hbase[mr] = (hp >> 3) * (CPP * 128 - 128) + ((hp << 4) + fqoff);
+        hbase[mr] = (int)__umul24((unsigned)hp >> 3, CPP * 128 - 128) + ((hp << 4) + fqoff);     // hp >= 0
       }
 #pragma unroll
       for (int gs = 0; gs < GPT; ++gs, ++sidx) {
         // stages issued after this one that may stay in flight while it is multiplied
         const int left = NSTAGE - 1 - sidx;
-        if (STAGES >= 4 && left >= 2) rows_wait_vmcnt<(STAGES >= 4 ? 2 : 0) * WV>();
-        else if (STAGES >= 3 && left >= 1) rows_wait_vmcnt<(STAGES >= 3 ? 1 : 0) * WV>();
-        else rows_wait_vmcnt<0>();
         // own LDS reads of the previous stage retired, then the block meets: this stage (and, the
         // first time, the halo tile issued before it) has landed for every wave and nobody still
         // reads the stage that is refilled next
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (STAGES >= 4 && left >= 2) rows_wait_barrier<(STAGES >= 4 ? 2 : 0) * WV>();
+        else if (STAGES >= 3 && left >= 1) rows_wait_barrier<(STAGES >= 3 ? 1 : 0) * WV>();
+        else rows_wait_barrier<0>();
         if (sidx + STAGES - 1 < NSTAGE) {
           issue_w(issue_stage);
           if (++issue_stage == STAGES) issue_stage = 0;
