@@ -75,10 +75,14 @@ __device__ __forceinline__ void rows_wait_barrier() {
 
 // STAGES: depth of the weight ring; SPS: K-steps (of 32) per stage, i.e. per barrier.
 // OCC: waves per SIMD the register allocation has to allow (blocks per CU the LDS admits).
+// EARLY (two stages of one K-step): every wave first moves its weight fragments of the stage into
+// registers, the block meets a second time and the stage is refilled at once with the step after
+// next - a refill then has two steps to arrive instead of one, with no third stage in LDS.
 template <int DT, int C, int W, int TR, int BN, int WAVES_M, int WAVES_N, int STAGES, int SPS,
-          int OCC, int EPI>
+          int OCC, int EPI, bool EARLY = false>
 __global__ __launch_bounds__(256, OCC)
 void conv_rows_kernel(const ConvParams p) {
+  static_assert(!EARLY || (STAGES == 2 && SPS == 1), "early refill: two stages of one K-step");
   static_assert(DT == DT_BF16 || DT == DT_F16, "16-bit element types");
   static_assert(WAVES_M * WAVES_N == 4, "four waves per block");
   static_assert(C == 64 || C == 128 || C == 256, "channels per pixel");
@@ -223,7 +227,7 @@ void conv_rows_kernel(const ConvParams p) {
     }
   };
 #pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s) issue_w(s);
+  for (int s = 0; s < (EARLY ? STAGES : STAGES - 1); ++s) issue_w(s);
 
   // ---- 3. fragment addresses --------------------------------------------------------------------
   const int fr = lane & 15, fq = lane >> 4;
@@ -266,6 +270,29 @@ void conv_rows_kernel(const ConvParams p) {
       for (int gs = 0; gs < GPT; ++gs, ++sidx) {
         // stages issued after this one that may stay in flight while it is multiplied
         const int left = NSTAGE - 1 - sidx;
+        if constexpr (EARLY) {
+          // this stage (and, the first time, the halo tile) has landed for every wave; the one issued
+          // after it may still be in flight
+          if (left >= 1) rows_wait_barrier<WV>();
+          else rows_wait_barrier<0>();
+          const uint8_t* ws = wring + read_stage * WBYTES;
+          u32x4 wf[NR], xf[MR];
+#pragma unroll
+          for (int nr = 0; nr < NR; ++nr) wf[nr] = *reinterpret_cast<const u32x4*>(ws + woff[nr]);
+          // every wave holds its fragments of the stage: refill it with the step after next
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if (sidx + 2 < NSTAGE) issue_w(read_stage);
+          read_stage ^= 1;
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr)
+            xf[mr] = *reinterpret_cast<const u32x4*>(halo + hbase[mr] + gs * 512);
+#pragma unroll
+          for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+              acc[nr][mr] = mfma_step<DT>(wf[nr], xf[mr], acc[nr][mr]);
+          continue;
+        }
         // own LDS reads of the previous stage retired, then the block meets: this stage (and, the
         // first time, the halo tile issued before it) has landed for every wave and nobody still
         // reads the stage that is refilled next
@@ -301,24 +328,25 @@ void conv_rows_kernel(const ConvParams p) {
                                                  mt, lane);
 }
 
-template <int DT, int C, int W, int TR, int BN, int WAVES_M, int WAVES_N, int STAGES, int SPS, int OCC>
+template <int DT, int C, int W, int TR, int BN, int WAVES_M, int WAVES_N, int STAGES, int SPS, int OCC,
+          bool EARLY>
 void launch_rows_dt(const ConvParams& p, hipStream_t stream) {
   const int grid = (p.M / (TR * W)) * (p.Cout / BN);
   if (p.stats_y)
-    hipLaunchKernelGGL((conv_rows_kernel<DT, C, W, TR, BN, WAVES_M, WAVES_N, STAGES, SPS, OCC, EPI_BSTATS>),
+    hipLaunchKernelGGL((conv_rows_kernel<DT, C, W, TR, BN, WAVES_M, WAVES_N, STAGES, SPS, OCC, EPI_BSTATS, EARLY>),
                        dim3(grid), dim3(256), 0, stream, p);
   else
-    hipLaunchKernelGGL((conv_rows_kernel<DT, C, W, TR, BN, WAVES_M, WAVES_N, STAGES, SPS, OCC, EPI_PLAIN>),
+    hipLaunchKernelGGL((conv_rows_kernel<DT, C, W, TR, BN, WAVES_M, WAVES_N, STAGES, SPS, OCC, EPI_PLAIN, EARLY>),
                        dim3(grid), dim3(256), 0, stream, p);
 }
 
 // `probe`: only answers whether the tile serves the descriptor
-template <int C, int W, int TR, int BN, int WAVES_M, int WAVES_N, int STAGES, int SPS, int OCC>
+template <int C, int W, int TR, int BN, int WAVES_M, int WAVES_N, int STAGES, int SPS, int OCC, bool EARLY = false>
 bool launch_rows(const ConvParams& p, hipStream_t stream, bool probe) {
   if (p.Cpix != C || p.W != W || p.H % TR || p.Cout % BN) return false;
   if (probe) return true;
-  if (p.dt == DT_F16) launch_rows_dt<DT_F16, C, W, TR, BN, WAVES_M, WAVES_N, STAGES, SPS, OCC>(p, stream);
-  else launch_rows_dt<DT_BF16, C, W, TR, BN, WAVES_M, WAVES_N, STAGES, SPS, OCC>(p, stream);
+  if (p.dt == DT_F16) launch_rows_dt<DT_F16, C, W, TR, BN, WAVES_M, WAVES_N, STAGES, SPS, OCC, EARLY>(p, stream);
+  else launch_rows_dt<DT_BF16, C, W, TR, BN, WAVES_M, WAVES_N, STAGES, SPS, OCC, EARLY>(p, stream);
   return true;
 }
 
@@ -479,7 +507,7 @@ bool rows_dispatch(const ConvParams& p, int cfg, hipStream_t stream, bool probe)
     case 50: return launch_rows<64, 56, 4, 64, 2, 2, 3, 2, 2>(p, stream, probe);     //  68 KB: a tap per stage
     case 51: return launch_rows<128, 28, 4, 128, 1, 4, 2, 2, 2>(p, stream, probe);   //  80 KB: half a tap per stage
     case 52: return launch_rows<64, 56, 4, 64, 2, 2, 2, 1, 3>(p, stream, probe);     //  52 KB LDS, 3 blocks / CU
-    case 53: return launch_rows<64, 56, 4, 64, 2, 2, 2, 2, 2>(p, stream, probe);     //  60 KB: a tap per stage, 2 stages
+    case 53: return launch_rows<64, 56, 4, 64, 2, 2, 2, 1, 3, true>(p, stream, probe);   //  52 KB, 3 blocks / CU, early refill
     default: return false;
   }
 }
