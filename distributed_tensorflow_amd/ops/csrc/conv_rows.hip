@@ -279,8 +279,10 @@ void conv_rows_kernel(const ConvParams p) {
           u32x4 wf[NR], xf[MR];
 #pragma unroll
           for (int nr = 0; nr < NR; ++nr) wf[nr] = *reinterpret_cast<const u32x4*>(ws + woff[nr]);
-          // every wave holds its fragments of the stage: refill it with the step after next
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          // every wave holds its fragments of the stage: refill it with the step after next (the
+          // vector-memory wait is the one above again: nothing new is in flight)
+          if (left >= 1) rows_wait_barrier<WV>();
+          else rows_wait_barrier<0>();
           if (sidx + 2 < NSTAGE) issue_w(read_stage);
           read_stage ^= 1;
 #pragma unroll
