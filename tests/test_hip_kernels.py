@@ -1126,12 +1126,13 @@ def test_dgrad_with_batchnorm_backward_prologue(case, cfg):
 
 @pytest.mark.parametrize("case,cfg", [
     ((3, 56, 56, 64, 3, 64, 1), 48), ((2, 56, 56, 64, 3, 128, 1), 50), ((1, 56, 56, 64, 3, 64, 1), 50),
-    ((3, 28, 28, 128, 3, 128, 1), 49), ((2, 28, 28, 128, 3, 256, 1), 51), ((5, 28, 28, 128, 3, 128, 1), 51)])
+    ((3, 28, 28, 128, 3, 128, 1), 49), ((2, 28, 28, 128, 3, 256, 1), 51), ((5, 28, 28, 128, 3, 128, 1), 51),
+    ((2, 56, 56, 64, 3, 64, 1), 53), ((61, 56, 56, 64, 3, 64, 1), 52)])
 def test_conv_whole_rows_kernel(case, cfg):
-  """conv_rows.hip (tile configurations 48..51: the large 3x3 unit-stride layers over whole image
-  rows, every input pixel fetched once into a halo tile): forward, data gradient and accumulating
-  data gradient against the PyTorch fp32 convolution - and the launches really are served by
-  that kernel, not by a fallback tile."""
+  """conv_rows.hip (tile configurations 48..53: the large 3x3 unit-stride layers over whole
+  image rows, every input pixel fetched once into a halo tile): forward, data gradient and
+  accumulating data gradient against the PyTorch fp32 convolution - and the launches really are
+  served by that kernel, not by a fallback tile."""
   native = _native()
   N, H, W, Cin, K, Cout, stride = case
   pad = same_padding(H, K, stride) + same_padding(W, K, stride)
@@ -1141,7 +1142,7 @@ def test_conv_whole_rows_kernel(case, cfg):
   assert native.ext().conv_rows_serves(fd)
   for d in g.dgrad(probe.data_ptr(), probe.data_ptr(), probe.data_ptr(), cfg=cfg):
     assert native.ext().conv_rows_serves(d) == (Cout == Cin)     # its data gradient has Cin outputs
-  assert not native.ext().conv_rows_serves(dict(fd, cfg=cfg ^ 1))  # the other layer's tile
+  assert not native.ext().conv_rows_serves(dict(fd, cfg=49 if Cin == 64 else 48))  # the other layer's tile
   _check_conv_cfg(case, cfg)
 
 
@@ -1243,6 +1244,57 @@ def test_stem_whole_rows_kernel(N, dtype):
   assert not native.ext().conv_rows_serves(small.fwd(probe.data_ptr(), probe.data_ptr(), probe.data_ptr(), cfg=54))
 
 
+@pytest.mark.parametrize("HW,C,cfgs", [(56, 64, (52, 53)), (28, 128, (49, 51))])
+def test_whole_rows_kernels_equal_the_general_kernel_at_a_large_batch(HW, C, cfgs):
+  """Every flavour of the whole-rows kernels against a pipeline tile at a batch with more tiles than
+  resident blocks (timing-dependent faults need many blocks in flight): forward + statistics, data gradient plain / with backward statistics / with an addend and
+  backward statistics.  An addend without statistics is not theirs: the launch is handed to the
+  pipeline tile and gives the same result."""
+  native = _native()
+  dev = torch.device("cuda")
+  N = 72
+  g = ConvGeom(N, HW, HW, C, 3, 3, C, 1, (1, 1, 1, 1))
+  gen = torch.Generator(device="cpu").manual_seed(HW)
+  x = _bf(torch.randn(N, HW, HW, C, generator=gen)).to(dev)
+  w = (torch.randn(3, 3, C, C, generator=gen) / math.sqrt(9 * C)).to(dev)
+  wf, wd = _pack(native, g, w, "fwd"), _pack(native, g, w, "dgrad")
+  y = _bf(torch.randn(N, HW, HW, C, generator=gen) * 1.5 + 0.7).to(dev)
+  add = _bf(torch.randn(N, HW, HW, C, generator=gen)).to(dev)
+  bits = torch.rand(N * HW * HW, C, generator=gen) > 0.4
+  mask = (bits.view(-1, C // 8, 8).to(torch.int32) << torch.arange(8)).sum(-1).to(torch.uint8)
+  mask = torch.cat([mask.flatten(), torch.zeros(4, dtype=torch.uint8)]).to(dev)
+
+  def run(cfg, kind, addend, stats):
+    out = torch.zeros(N, HW, HW, C, dtype=torch.bfloat16, device=dev)
+    st = torch.zeros(32, 2, C, device=dev)
+    if kind == "fwd":
+      descs = [g.fwd(x.data_ptr(), wf.data_ptr(), out.data_ptr(), cfg=cfg, stats=st.data_ptr(), stats_replicas=32)]
+    else:
+      descs = g.dgrad(x.data_ptr(), wd.data_ptr(), out.data_ptr(), cfg=cfg, addend=add.data_ptr() if addend else None)
+      if stats:
+        for d in descs:
+          d.update(stats=st.data_ptr(), stats_replicas=32, stats_y=y.data_ptr(), stats_mask=mask.data_ptr())
+    for d in descs:
+      native.run_op("conv", d)
+    torch.cuda.synchronize()
+    return out, st.sum(0)
+
+  for kind, addend, stats in (("fwd", False, True), ("dgrad", False, False), ("dgrad", False, True),
+                              ("dgrad", True, True), ("dgrad", True, False)):
+    ref, ref_st = run(30, kind, addend, stats)
+    for cfg in cfgs:
+      probe = (g.fwd(1, 2, 3, cfg=cfg) if kind == "fwd" else g.dgrad(1, 2, 3, cfg=cfg, addend=4 if addend else None)[0])
+      if stats and kind == "dgrad":
+        probe = dict(probe, stats=5, stats_y=6)
+      assert native.ext().conv_rows_serves(probe) == (not (addend and not stats)), (cfg, kind, addend, stats)
+      for _ in range(2):
+        out, st = run(cfg, kind, addend, stats)
+        tol = 2.0 ** -6 * ref.float().abs() + 2e-2
+        assert int(((out.float() - ref.float()).abs() > tol).sum()) == 0, (cfg, kind, addend, stats)
+        assert torch.allclose(st, ref_st, rtol=1e-3, atol=1e-3 * ref_st.abs().max().item() + 1e-2)
+
+
+
 def _affine_relu(x, scale, shift):
   """What the BatchNorm apply sweep would have written: relu(fma(x, scale, shift)) in fp32, rounded
   (the product is not rounded on its own: computed in double and rounded once)."""
@@ -1250,7 +1302,9 @@ def _affine_relu(x, scale, shift):
 
 
 @pytest.mark.parametrize("case,cfg", [((3, 56, 56, 64, 3, 64, 1), 52), ((2, 56, 56, 64, 3, 64, 1), 48),
-                                      ((3, 28, 28, 128, 3, 128, 1), 49), ((2, 28, 28, 128, 3, 128, 1), 51)])
+                                      ((3, 28, 28, 128, 3, 128, 1), 49), ((2, 28, 28, 128, 3, 128, 1), 51),
+                                      ((2, 56, 56, 64, 3, 64, 1), 53), ((59, 56, 56, 64, 3, 64, 1), 52),
+                                      ((79, 28, 28, 128, 3, 128, 1), 49)])
 def test_whole_rows_kernels_normalise_their_input_inside_the_tile(case, cfg):
   """conv_rows.hip with `in_scale` / `in_shift`: BatchNorm + ReLU of the layer in front applied to the halo
   tile in LDS.  The result equals, bit for bit, the same launch on a tensor normalised beforehand
