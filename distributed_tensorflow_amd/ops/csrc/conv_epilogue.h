@@ -362,6 +362,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
             v2 += lo16<DT>(a.y); v3 += hi16<DT>(a.y);
             v4 += lo16<DT>(a.z); v5 += hi16<DT>(a.z);
             v6 += lo16<DT>(a.w); v7 += hi16<DT>(a.w);
+            // The eight sums stay eight separate registers up to the conversions.  Left alone the
+            // compiler pairs them as v_pk_add_f32 with operand selects and regroups the pairs with
+            // v_pk_mov_b32 one wait state later; in the whole-rows kernels that sequence lost the
+            // addend of a lane's last channel in lanes 48 - 63 - ~2 500 of 51 million elements at
+            // batch 256, different ones from launch to launch (scripts/debug/rows_stress.py).
+            asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
           }
           if (do_relu) {
             v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);

@@ -490,11 +490,6 @@ bool launch_stem_rows(const ConvParams& p, hipStream_t stream, bool probe) {
 bool conv_rows_supports(const ConvParams& p) {
   const bool fwd_taps = p.dhs == 1 && p.dws == 1 && p.dh0 == -1 && p.dw0 == -1;
   const bool bwd_taps = p.dhs == -1 && p.dws == -1 && p.dh0 == 1 && p.dw0 == 1;
-  // (an addend without backward statistics goes to the pipeline tiles: in this kernel the plain
-  // epilogue's addend sum lost elements of lanes 48 - 63 at large batches - 2 500 of 51 million at
-  // batch 256, different ones from launch to launch, while every other flavour equals the general
-  // kernels bit for bit; scripts/debug/rows_stress.py)
-  if (p.addend && !p.stats_y) return false;
   return p.dt != DT_F32 && !p.scale && !p.bias && !p.pro.sums && !p.bpro.sums &&
          p.TI == 3 && p.TJ == 3 && (fwd_taps || bwd_taps) && p.Ctap == p.Cpix &&
          p.ISH == 1 && p.ISW == 1 && p.OH == p.H && p.OW == p.W && p.OSH == 1 && p.OSW == 1 &&

@@ -1248,8 +1248,8 @@ def test_stem_whole_rows_kernel(N, dtype):
 def test_whole_rows_kernels_equal_the_general_kernel_at_a_large_batch(HW, C, cfgs):
   """Every flavour of the whole-rows kernels against a pipeline tile at a batch with more tiles than
   resident blocks (timing-dependent faults need many blocks in flight): forward + statistics, data gradient plain / with backward statistics / with an addend and
-  backward statistics.  An addend without statistics is not theirs: the launch is handed to the
-  pipeline tile and gives the same result."""
+  backward statistics, with an addend alone (the flavour whose sums the compiler once paired into a
+  sequence that lost elements at large batches)."""
   native = _native()
   dev = torch.device("cuda")
   N = 72
@@ -1286,7 +1286,7 @@ def test_whole_rows_kernels_equal_the_general_kernel_at_a_large_batch(HW, C, cfg
       probe = (g.fwd(1, 2, 3, cfg=cfg) if kind == "fwd" else g.dgrad(1, 2, 3, cfg=cfg, addend=4 if addend else None)[0])
       if stats and kind == "dgrad":
         probe = dict(probe, stats=5, stats_y=6)
-      assert native.ext().conv_rows_serves(probe) == (not (addend and not stats)), (cfg, kind, addend, stats)
+      assert native.ext().conv_rows_serves(probe), (cfg, kind, addend, stats)
       for _ in range(2):
         out, st = run(cfg, kind, addend, stats)
         tol = 2.0 ** -6 * ref.float().abs() + 2e-2
