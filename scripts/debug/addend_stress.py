@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Data gradients with an addend (the residual sum of the backward pass) at the batch size of the
-training step: every tile family against every other, several launches each - a timing-dependent
+"""Data gradients with an addend (the residual sum of the backward pass) and forward launches with
+BatchNorm statistics at the batch size of the training step: every tile family against every other, several launches each - a timing-dependent
 fault shows as a difference:  python scripts/debug/addend_stress.py [N=256]"""
 import math
 import os
@@ -55,5 +55,30 @@ for (H, Cin, K, Cout, stride, cfgs) in CASES:
           faults += 1
           print("%dx%dx%d k%d -> %d%s: tile %d launch %d differs from tile %d in %d elements (max %.3g)"
                 % (H, H, Cin, K, Cout, " masked" if with_mask else "", cfg, rep, cfgs[0], n, dlt.max().item()), flush=True)
+  # the forward launch of the same layer with the BatchNorm statistics in its epilogue
+  x = T._bf(torch.randn(N, H, H, Cin, generator=gen)).to(dev)
+  wf = T._pack(native, g, w, "fwd")
+  ref = ref_st = None
+  for cfg in cfgs:
+    for rep in range(2):
+      out = torch.zeros(g.output_shape, dtype=torch.bfloat16, device=dev)
+      st = torch.zeros(32, 2, Cout, device=dev)
+      try:
+        native.run_op("conv", g.fwd(x.data_ptr(), wf.data_ptr(), out.data_ptr(), cfg=cfg, stats=st.data_ptr(),
+                                    stats_replicas=32))
+      except ValueError:
+        break
+      torch.cuda.synchronize()
+      st = st.sum(0)
+      if ref is None:
+        ref, ref_st = out, st
+        continue
+      dlt = (out.float() - ref.float()).abs()
+      n = int((dlt > 2.0 ** -6 * ref.float().abs() + 2e-2).sum())
+      ok_st = torch.allclose(st, ref_st, rtol=1e-3, atol=1e-3 * ref_st.abs().max().item() + 1e-2)
+      if n or not ok_st:
+        faults += 1
+        print("%dx%dx%d k%d -> %d forward: tile %d launch %d differs from tile %d in %d elements, statistics %s"
+              % (H, H, Cin, K, Cout, cfg, rep, cfgs[0], n, "ok" if ok_st else "OFF"), flush=True)
   print("%dx%dx%d k%d -> %d done" % (H, H, Cin, K, Cout), flush=True)
 print("FAULTS: %d" % faults)
