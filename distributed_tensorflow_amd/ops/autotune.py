@@ -159,8 +159,11 @@ def _wgrad_candidates(desc: Dict) -> List[Tuple[int, int]]:
       for lg, g in ((1, 2), (2, 4)):
         if s >= g and not (c == 8 and g == 4) and (c + 16 * lg, -(-s // g)) not in out:
           out.extend(with_depths(c + 16 * lg, -(-s // g)))
-  # 192: the whole-rows kernel of conv_wgrad_rows.hip (56x56x64 and 28x28x128 3x3, unit stride);
-  # the split count is kept for the fallback tile
+  # 192: the whole-rows kernels of conv_wgrad_rows.hip (56x56x64 and 28x28x128 3x3, unit stride; the
+  # merged-tap ImageNet stem); the split count is kept for the fallback tile
+  if (desc.get("TI"), desc.get("TJ"), desc.get("Ctap"), desc.get("Cpix"), cout, desc.get("OW"),
+      desc.get("TJreal")) == (7, 1, 32, 4, 64, 112, 7) and desc.get("batch") is None and out:
+    out.append((192, out[0][1]))
   if (desc.get("TI"), desc.get("TJ"), desc.get("Cpix"), desc.get("W"), cout) in ((3, 3, 64, 56, 64),
                                                                                  (3, 3, 128, 28, 128)) \
       and desc.get("ISH", 1) == 1 and desc.get("batch") is None and out:

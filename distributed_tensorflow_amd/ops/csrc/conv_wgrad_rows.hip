@@ -308,8 +308,152 @@ bool launch_rows(const WgradParams& p, hipStream_t stream, bool probe) {
   return true;
 }
 
+// ---- the ImageNet stem: 7x7 stride 2 on the 4-channel image stored with its zero border -------------
+//
+//   dW[i][j][ci][co] += sum over output pixels (r, c) of X[2 r + i][2 c + j][ci] * dY[r][c][co]
+//
+// In the merged-tap form of the stem (conv_plan.py) a row of the [K][64] gradient is (i, j, ci) with
+// j = 0 .. 7, ci = 0 .. 3 (tap 7 and channel 3 are padding): 7 x 32 = 224 rows, 14 MFMA tiles of 16.
+// The general kernel fetches the 64-byte window of every (pixel, kernel row) from L2 - each input
+// pixel 28 times, 1.4 GB per launch next to the 0.4 GB of dY, 191 us at the rate of the L2.  Here
+// a block takes pairs of output rows (224 pixels = 7 reduction steps of 32): the 9 input rows they
+// touch sit in LDS once (2 KB apart) next to the dY tile, and the fragment of (kernel row i, taps
+// 4 h .. 4 h + 3) for output pixel c is the 32 bytes at row 2 r + i, pixel 2 c + 4 h: windows of
+// neighbouring pixels overlap, so there is nothing to swizzle - lanes that meet at an address
+// share the read.  Wave w owns the MFMA tiles w, w + 4, w + 8 (, w + 12) and all 64 output channels.
+constexpr int SW_OW = 112, SW_PIX = 2 * SW_OW, SW_KS = SW_PIX / 32, SW_PITCH = 2048, SW_HROUNDS = 5;
+constexpr int SW_MT = 14;                            // MFMA tiles of gradient rows: (kernel row, half of its taps)
+
+template <int DT>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_stem_rows_kernel(const WgradParams p, int tiles_per_block,
+                                                                      int ntiles) {
+  constexpr int XBYTES = SW_HROUNDS * 4096, YBYTES = SW_KS * 4096;
+  static_assert(9 * SW_PITCH <= XBYTES && SW_PIX % 32 == 0, "tile shape");
+  typedef uint16_t T;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  __shared__ __attribute__((aligned(16))) uint8_t smem[XBYTES + YBYTES];
+  uint8_t* xs = smem;
+  uint8_t* ys = smem + XBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const T* __restrict__ gx = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ gy = reinterpret_cast<const T*>(p.dy);
+  const T* zero_page = reinterpret_cast<const T*>(g_zero_page_wr);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int g = lane >> 4, idx = lane & 15, qq = idx >> 2, pp = idx & 3;
+  const int yrow = tid >> 3;
+  const int ych = ((((tid & 7) >> 1) ^ swz64(yrow)) << 1) | (tid & 1);
+  const int tiles_per_img = p.OH >> 1;
+  const int row_chunks = (p.W * 4) >> 3;             // 16-byte chunks of a stored input row
+  const int t0 = blockIdx.x * tiles_per_block;
+  const int t1 = min(t0 + tiles_per_block, ntiles);
+  for (int t = t0; t < t1; ++t) {
+    const int tt = p.rev ? ntiles - 1 - t : t;
+    const int n = tt / tiles_per_img, r0 = (tt - n * tiles_per_img) * 2;
+    if (t != t0) {                 // every wave has read the previous tile
+      dma_wait_all();
+      __syncthreads();
+    }
+    // ---- 9 input rows: 16-byte position q = chunk (q % 128) of input row 2 r0 + q / 128 ----------------
+#pragma unroll
+    for (int it = 0; it < SW_HROUNDS; ++it) {
+      const int q = (it * 4 + wave) * 64 + lane;
+      const int hr = q >> 7, ch = q & 127;
+      const bool ok = hr < 9 && ch < row_chunks;
+      const T* src = ok ? gx + (((size_t)(n * p.H + 2 * r0 + hr) * p.W) * 4 + ch * 8) : zero_page;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + (it * 4 + wave) * 1024), 16, 0, 0);
+    }
+    // ---- dY: two output rows = 224 consecutive pixels, 7 step tiles of [32 pixels][64 channels] --------
+    const size_t pix0 = (size_t)(n * p.OH + r0) * SW_OW;
+#pragma unroll
+    for (int s = 0; s < SW_KS; ++s) {
+      const T* src = gy + ((pix0 + s * 32 + yrow) * (size_t)p.ldy + ych * 8);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ys + s * 4096 + wave * 1024), 16, 0, 0);
+    }
+    dma_wait_all();
+    __syncthreads();
+
+#pragma unroll 1
+    for (int s = 0; s < SW_KS; ++s) {
+      const uint8_t* yt = ys + s * 4096;
+      bf16x8 yf[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int ra = 8 * g + qq, rb = ra + 4;
+        yf[b] = tr_pair(yt + ra * 128 + (((b ^ swz64(ra)) << 5) | (pp << 3)),
+                        yt + rb * 128 + (((b ^ swz64(rb)) << 5) | (pp << 3)));
+      }
+      const int q0 = s * 32 + 8 * g + qq, q1 = q0 + 4;
+      const int rr0 = q0 >= SW_OW ? 1 : 0, rr1 = q1 >= SW_OW ? 1 : 0;
+      // input pixel 2 c + pp of input row 2 rr (kernel row and tap half are added per tile)
+      const uint8_t* b0 = xs + (2 * rr0) * SW_PITCH + ((2 * (q0 - rr0 * SW_OW) + pp) << 3);
+      const uint8_t* b1 = xs + (2 * rr1) * SW_PITCH + ((2 * (q1 - rr1 * SW_OW) + pp) << 3);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int mt = wave + 4 * a;                 // MFMA tile: kernel row mt / 2, taps 4 (mt % 2) ..
+        if (mt < SW_MT) {
+          const int off = (mt >> 1) * SW_PITCH + ((mt & 1) << 5);
+          const bf16x8 xf = tr_pair(b0 + off, b1 + off);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = mfma32<DT>(xf, yf[b], acc[a][b]);
+        }
+      }
+    }
+  }
+  if (t0 >= t1) return;
+
+  // ---- the block's gradient: row (kernel row i, tap j, channel ci) of the real [7][7][3][64] tensor ---
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int mt = wave + 4 * a;
+    if (mt >= SW_MT) continue;
+    const int i = mt >> 1, j = ((mt & 1) << 2) + fq;
+    if (j >= 7) continue;                            // the eighth tap is padding
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {                    // (the fourth channel is padding)
+      float* row = p.dw + (size_t)((i * 7 + j) * 3 + r) * 64;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (p.debug_plain_store) row[b * 16 + fr] = acc[a][b][r];
+        else atomicAdd(row + b * 16 + fr, acc[a][b][r]);
+      }
+    }
+  }
+}
+
+bool stem_rows_dispatch(const WgradParams& p, hipStream_t stream, bool probe) {
+  if (p.batch != nullptr || p.x_scale != nullptr || (p.dt != DT_BF16 && p.dt != DT_F16)) return false;
+  if (p.TI != 7 || p.TJ != 1 || p.Ctap != 32 || p.Cpix != 4 || p.Cpad != 4 || p.Creal != 3 || p.TJpad != 8 ||
+      p.TJreal != 7 || p.ISH != 2 || p.ISW != 2 || p.dh0 != 0 || p.dw0 != 0 || p.dhs != 1)
+    return false;
+  if (p.OW != SW_OW || p.OH % 2 || p.Cout != 64 || p.ldy != 64 || p.W % 2 || p.W * 8 > SW_PITCH ||
+      p.W < 2 * (SW_OW - 1) + 8 || p.H < 2 * (p.OH - 1) + 7)
+    return false;
+  if (probe) return true;
+  const int ntiles = p.N * (p.OH / 2);
+  int blocks = 768;                                  // three blocks on each of the 256 compute units
+  if (blocks > ntiles) blocks = ntiles;
+  const int tpb = (ntiles + blocks - 1) / blocks;
+  blocks = (ntiles + tpb - 1) / tpb;
+  if (p.dt == DT_F16)
+    hipLaunchKernelGGL(conv_wgrad_stem_rows_kernel<DT_F16>, dim3(blocks), dim3(256), 0, stream, p, tpb, ntiles);
+  else
+    hipLaunchKernelGGL(conv_wgrad_stem_rows_kernel<DT_BF16>, dim3(blocks), dim3(256), 0, stream, p, tpb, ntiles);
+  return true;
+}
+
 bool rows_dispatch(const WgradParams& p, int cfg, hipStream_t stream, bool probe) {
   if (cfg != WGRAD_ROWS_CFG) return false;
+  if (p.TI == 7) return stem_rows_dispatch(p, stream, probe);
   if (p.batch != nullptr || (p.dt != DT_BF16 && p.dt != DT_F16)) return false;
   if (p.TI != 3 || p.TJ != 3 || p.ISH != 1 || p.ISW != 1 || p.dh0 != -1 || p.dw0 != -1 || p.dhs != 1 ||
       p.dws != 1 || p.OH != p.H || p.OW != p.W)
@@ -327,7 +471,7 @@ bool rows_dispatch(const WgradParams& p, int cfg, hipStream_t stream, bool probe
 }  // namespace
 
 // 3x3, unit stride, padding 1, 16-bit elements, one layer per launch: 56x56x64 -> 64 and
-// 28x28x128 -> 128
+// 28x28x128 -> 128; the 7x7 stride-2 stem in its merged-tap form
 bool wgrad_rows_serves(const WgradParams& p, int cfg) { return rows_dispatch(p, cfg, nullptr, true); }
 
 size_t wgrad_rows_workspace_floats() { return WR_WS_FLOATS; }

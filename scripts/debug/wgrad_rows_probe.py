@@ -45,5 +45,23 @@ def main():
             % (N, HW, HW, C, cfg, t, 2 * N * HW * HW * C * 9 * C / t / 1e6, ta, tp, tn), flush=True)
 
 
+def stem():
+  """The 7x7 stride-2 stem (merged-tap form): whole-rows kernel against the tiles of the general one."""
+  dev = torch.device("cuda")
+  N = 256
+  g = ConvGeom(N, 224, 224, 3, 7, 7, 64, 2, (3, 3, 3, 3), mode="merged")
+  x = torch.randn(g.input_shape, device=dev).to(torch.bfloat16)
+  dy = torch.randn(N, 112, 112, 64, device=dev).to(torch.bfloat16)
+  dw = torch.zeros(7, 7, 3, 64, device=dev)
+  for cfg, splits in ((192, 1), (1, 768), (1, 384), (3, 768)):
+    d = g.wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), cfg=cfg, splits=splits)
+    t = timeit(lambda: native.run_op("wgrad", d))
+    tp = timeit(lambda: native.run_op("wgrad", dict(d, debug_plain_store=1)))
+    print("stem N=%d cfg %d splits %d: %.1f us, plain stores instead of atomics %.1f us" % (N, cfg, splits, t, tp), flush=True)
+
+
 if __name__ == "__main__":
-  main()
+  if len(sys.argv) > 1 and sys.argv[1] == "stem":
+    stem()
+  else:
+    main()

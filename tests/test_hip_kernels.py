@@ -1244,6 +1244,44 @@ def test_stem_whole_rows_kernel(N, dtype):
   assert not native.ext().conv_rows_serves(small.fwd(probe.data_ptr(), probe.data_ptr(), probe.data_ptr(), cfg=54))
 
 
+@pytest.mark.parametrize("N,dtype", [(2, torch.bfloat16), (5, torch.float16), (19, torch.bfloat16)])
+def test_stem_weight_gradient_whole_rows_kernel(N, dtype):
+  """conv_wgrad_rows.hip on the 7x7 stride-2 stem (merged-tap form, cfg 192: nine input rows and two
+  rows of dY in LDS, every window read out of them) against the PyTorch fp32 weight gradient and against
+  the general kernel; it accumulates; a stem of another width goes to the general kernel."""
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator().manual_seed(N)
+  H = 224
+  dti = {torch.bfloat16: 0, torch.float16: 1}[dtype]
+  g = ConvGeom(N, H, H, 3, 7, 7, 64, 2, (3, 3, 3, 3), mode="merged", dt=dti)
+  img = torch.randn(N, H, H, 3, generator=gen).to(dev)
+  xin = torch.zeros(g.input_shape, dtype=dtype, device=dev)
+  native.run_op("preprocess_pad", dict(N=N, H=H, W=H, Cin=3, pt=3, pl=3, OH=g.Hs, OW=g.Ws, Cpad=4, dt=dti,
+                                       out=xin.data_ptr(), **{"in": img.data_ptr()}))
+  dy = torch.randn(N, 112, 112, 64, generator=gen).to(dtype).to(dev)
+  xr = xin[:, 3:3 + H, 3:3 + H, :3].float()
+  wr = torch.zeros(7, 7, 3, 64, device=dev).requires_grad_(True)
+  _ref_conv(xr, wr, 2, (3, 3, 3, 3)).backward(dy.float())
+  before = torch.randn(7, 7, 3, 64, generator=gen).to(dev)
+  dw = before.clone()
+  d = g.wgrad(xin.data_ptr(), dy.data_ptr(), dw.data_ptr(), cfg=192)
+  assert native.ext().wgrad_rows_serves(d)
+  native.run_op("wgrad", d)
+  torch.cuda.synchronize()
+  scale = wr.grad.abs().max().item()
+  assert (dw - before - wr.grad).abs().max().item() <= 2e-3 * scale + 1e-3
+  dw2 = torch.zeros_like(dw)
+  native.run_op("wgrad", g.wgrad(xin.data_ptr(), dy.data_ptr(), dw2.data_ptr(), cfg=1, splits=16))
+  native.run_op("wgrad", dict(d, dw=dw.data_ptr(), rev=1))          # back to front, on top
+  torch.cuda.synchronize()
+  assert (dw2 - wr.grad).abs().max().item() <= 2e-3 * scale + 1e-3
+  assert (dw - before - 2 * wr.grad).abs().max().item() <= 4e-3 * scale + 2e-3
+  small = ConvGeom(N, 64, 64, 3, 7, 7, 64, 2, (3, 3, 3, 3), mode="merged", dt=dti)
+  probe = torch.zeros(16, device=dev)
+  assert not native.ext().wgrad_rows_serves(small.wgrad(probe.data_ptr(), probe.data_ptr(), probe.data_ptr(), cfg=192))
+
+
 @pytest.mark.parametrize("HW,C,cfgs", [(56, 64, (52, 53)), (28, 128, (49, 51))])
 def test_whole_rows_kernels_equal_the_general_kernel_at_a_large_batch(HW, C, cfgs):
   """Every flavour of the whole-rows kernels against a pipeline tile at a batch with more tiles than
