@@ -432,6 +432,9 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_stem_rows_kernel(const Wgra
 
 bool stem_rows_dispatch(const WgradParams& p, hipStream_t stream, bool probe) {
   if (p.batch != nullptr || p.x_scale != nullptr || (p.dt != DT_BF16 && p.dt != DT_F16)) return false;
+  // one split is how the engine asks for a summation order that does not depend on timing: the
+  // blocks of this kernel add their gradients with atomics, so that request goes to the general kernel
+  if (p.splits == 1) return false;
   if (p.TI != 7 || p.TJ != 1 || p.Ctap != 32 || p.Cpix != 4 || p.Cpad != 4 || p.Creal != 3 || p.TJpad != 8 ||
       p.TJreal != 7 || p.ISH != 2 || p.ISW != 2 || p.dh0 != 0 || p.dw0 != 0 || p.dhs != 1)
     return false;

@@ -53,7 +53,7 @@ def stem():
   x = torch.randn(g.input_shape, device=dev).to(torch.bfloat16)
   dy = torch.randn(N, 112, 112, 64, device=dev).to(torch.bfloat16)
   dw = torch.zeros(7, 7, 3, 64, device=dev)
-  for cfg, splits in ((192, 1), (1, 768), (1, 384), (3, 768)):
+  for cfg, splits in ((192, 96), (1, 768), (1, 384), (3, 768)):
     d = g.wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), cfg=cfg, splits=splits)
     t = timeit(lambda: native.run_op("wgrad", d))
     tp = timeit(lambda: native.run_op("wgrad", dict(d, debug_plain_store=1)))

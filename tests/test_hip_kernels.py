@@ -1280,6 +1280,15 @@ def test_stem_weight_gradient_whole_rows_kernel(N, dtype):
   small = ConvGeom(N, 64, 64, 3, 7, 7, 64, 2, (3, 3, 3, 3), mode="merged", dt=dti)
   probe = torch.zeros(16, device=dev)
   assert not native.ext().wgrad_rows_serves(small.wgrad(probe.data_ptr(), probe.data_ptr(), probe.data_ptr(), cfg=192))
+  # one split = a fixed summation order: not this kernel's (its blocks add with atomics); the general
+  # kernel serves the launch and repeats bit for bit
+  assert not native.ext().wgrad_rows_serves(dict(d, splits=1))
+  once, twice = torch.zeros_like(dw), torch.zeros_like(dw)
+  for out in (once, twice):
+    native.run_op("wgrad", dict(d, dw=out.data_ptr(), splits=1))
+  torch.cuda.synchronize()
+  assert torch.equal(once, twice)
+  assert (once - wr.grad).abs().max().item() <= 2e-3 * scale + 1e-3
 
 
 @pytest.mark.parametrize("HW,C,cfgs", [(56, 64, (52, 53)), (28, 128, (49, 51))])
