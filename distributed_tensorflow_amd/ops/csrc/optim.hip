@@ -156,6 +156,35 @@ __global__ __launch_bounds__(256) void preprocess_pad_kernel(const float* __rest
   }
 }
 
+// The ImageNet case - three fp32 channels to four 16-bit ones - with a thread per PAIR of output
+// pixels: six coalesced float loads and one 16-byte store instead of four 2-byte stores per pixel
+// (the staging of a batch sits alone at the head of the step: 86 -> 6x us for 256 x 224 x 224).
+template <int DT>
+__global__ __launch_bounds__(256) void preprocess_pad_rgb_kernel(const float* __restrict__ in,
+                                                                 u32x4* __restrict__ out, int N, int H,
+                                                                 int W, int pt, int pl, int OH, int OW) {
+  const int pairs = OW >> 1;
+  const size_t total = (size_t)N * OH * pairs;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int op = (int)(r % pairs); r /= pairs;
+    const int oh = (int)(r % OH);
+    const int n = (int)(r / OH);
+    const int h = oh - pt, w0 = 2 * op - pl;
+    const bool row = (unsigned)h < (unsigned)H;
+    const bool in0 = row && (unsigned)w0 < (unsigned)W, in1 = row && (unsigned)(w0 + 1) < (unsigned)W;
+    const float* src = in + ((size_t)(n * H + (row ? h : 0)) * W) * 3;
+    float a[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
+    if (in0) { a[0] = src[w0 * 3]; a[1] = src[w0 * 3 + 1]; a[2] = src[w0 * 3 + 2]; }
+    if (in1) { b[0] = src[w0 * 3 + 3]; b[1] = src[w0 * 3 + 4]; b[2] = src[w0 * 3 + 5]; }
+    u32x4 o;
+    o.x = pack2<DT>(a[0], a[1]); o.y = pack2<DT>(a[2], 0.f);
+    o.z = pack2<DT>(b[0], b[1]); o.w = pack2<DT>(b[2], 0.f);
+    out[i] = o;
+  }
+}
+
 // Zero fill as a kernel (not hipMemsetAsync): inside a captured hipGraph a large memset node
 // was observed to race with the atomics of the kernel that follows it; a kernel node is
 // ordered like every other launch.
@@ -204,6 +233,16 @@ void launch_pack_weights(const float* params, void* packed, const PackDesc* desc
 void launch_preprocess_pad(const float* in, void* out, int N, int H, int W, int Cin, int pt,
                            int pl, int OH, int OW, int Cpad, int dt, hipStream_t s) {
   if (Cpad < Cin) throw std::invalid_argument("preprocess_pad: Cpad < Cin");
+  if (Cin == 3 && Cpad == 4 && OW % 2 == 0 && dt != DT_F32 && ((uintptr_t)out & 15) == 0) {
+    const size_t pairs = (size_t)N * OH * (OW / 2);
+    if (dt == DT_F16)
+      hipLaunchKernelGGL(preprocess_pad_rgb_kernel<DT_F16>, dim3(grid_for(pairs)), dim3(256), 0, s, in,
+                         reinterpret_cast<u32x4*>(out), N, H, W, pt, pl, OH, OW);
+    else
+      hipLaunchKernelGGL(preprocess_pad_rgb_kernel<DT_BF16>, dim3(grid_for(pairs)), dim3(256), 0, s, in,
+                         reinterpret_cast<u32x4*>(out), N, H, W, pt, pl, OH, OW);
+    return;
+  }
   DTF_DT_SWITCH(dt, hipLaunchKernelGGL(preprocess_pad_kernel<DT>,
                                        dim3(grid_for((size_t)N * OH * OW)), dim3(256), 0, s, in,
                                        out, N, H, W, Cin, pt, pl, OH, OW, Cpad));

@@ -1244,6 +1244,26 @@ def test_stem_whole_rows_kernel(N, dtype):
   assert not native.ext().conv_rows_serves(small.fwd(probe.data_ptr(), probe.data_ptr(), probe.data_ptr(), cfg=54))
 
 
+@pytest.mark.parametrize("N,H,W,dtype", [(3, 224, 224, torch.bfloat16), (2, 32, 30, torch.float16), (1, 9, 7, torch.bfloat16)])
+def test_preprocess_pad_rgb(N, H, W, dtype):
+  """Input staging: fp32 RGB images to the 16-bit 4-channel tensor with its zero border (the pair-of-pixels
+  kernel for an even padded width, the per-pixel kernel otherwise), element for element."""
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator().manual_seed(N * H)
+  img = (torch.randn(N, H, W, 3, generator=gen) * 60 + 100).to(dev)
+  pt, pl = 3, 3
+  OH, OW = H + 6, W + (6 if W % 2 == 0 else 5)
+  dti = {torch.bfloat16: 0, torch.float16: 1}[dtype]
+  out = torch.full((N, OH, OW, 4), float("nan"), dtype=dtype, device=dev)
+  native.run_op("preprocess_pad", dict(N=N, H=H, W=W, Cin=3, pt=pt, pl=pl, OH=OH, OW=OW, Cpad=4, dt=dti,
+                                       out=out.data_ptr(), **{"in": img.data_ptr()}))
+  torch.cuda.synchronize()
+  want = torch.zeros(N, OH, OW, 4, dtype=dtype, device=dev)
+  want[:, pt:pt + H, pl:pl + W, :3] = img.to(dtype)
+  assert torch.equal(out, want)
+
+
 @pytest.mark.parametrize("N,dtype", [(2, torch.bfloat16), (5, torch.float16), (19, torch.bfloat16)])
 def test_stem_weight_gradient_whole_rows_kernel(N, dtype):
   """conv_wgrad_rows.hip on the 7x7 stride-2 stem (merged-tap form, cfg 192: nine input rows and two
