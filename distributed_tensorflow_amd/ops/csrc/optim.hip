@@ -122,6 +122,27 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
   }
   // mode 1: dst[ci][ti][tj][cop], cop contiguous in both tensors
   const int64_t base = ((int64_t)blockIdx.x - d.first_block) * PACK_PER_BLOCK;
+  if (DT != DT_F32 && d.CoutPad % 8 == 0 && d.Cout % 4 == 0 && d.src_off % 4 == 0 && d.dst_off % 8 == 0 &&
+      d.count < (1ll << 31)) {
+    // eight consecutive output channels per thread: one index decode in 32-bit arithmetic, two
+    // 16-byte loads, one 16-byte store (the per-element form spends its time in 64-bit divisions)
+    const int i = (int)base + (int)threadIdx.x * 8;
+    if (i >= (int)d.count) return;
+    int r = i;
+    const int cop = r % d.CoutPad; r /= d.CoutPad;
+    const int tj = r % d.TJ; r /= d.TJ;
+    const int ti = r % d.TI;
+    const int ci = r / d.TI;
+    const float* row = src + ((int64_t)(ti * d.TJ + tj) * d.Cin + ci) * d.Cout + cop;
+    f4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+    if (cop + 4 <= d.Cout) lo = *reinterpret_cast<const f4*>(row);
+    if (cop + 8 <= d.Cout) hi = *reinterpret_cast<const f4*>(row + 4);
+    u32x4 o;
+    o.x = pack2<DT>(lo[0], lo[1]); o.y = pack2<DT>(lo[2], lo[3]);
+    o.z = pack2<DT>(hi[0], hi[1]); o.w = pack2<DT>(hi[2], hi[3]);
+    *reinterpret_cast<u32x4*>(dst + i) = o;
+    return;
+  }
   for (int e = 0; e < 8; ++e) {
     const int64_t i = base + e * 256 + threadIdx.x;
     if (i >= d.count) return;
