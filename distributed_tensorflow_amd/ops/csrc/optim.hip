@@ -109,6 +109,17 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
       }
     }
     __syncthreads();
+    if (DT != DT_F32 && d.Cpad % 8 == 0 && d.dst_off % 8 == 0) {
+      // eight consecutive cp of one output channel per thread: one 16-byte store
+      const int r8 = (threadIdx.x & 3) * 8, c = threadIdx.x >> 2, co = co0 + c, cp = cp0 + r8;
+      if (cp < d.Cpad && co < d.Cout) {
+        u32x4 o;
+        o.x = pack2<DT>(tile[r8 + 0][c], tile[r8 + 1][c]); o.y = pack2<DT>(tile[r8 + 2][c], tile[r8 + 3][c]);
+        o.z = pack2<DT>(tile[r8 + 4][c], tile[r8 + 5][c]); o.w = pack2<DT>(tile[r8 + 6][c], tile[r8 + 7][c]);
+        *reinterpret_cast<u32x4*>(dst + ((((int64_t)co * d.TI + ti) * d.TJpad + tjp) * d.Cpad + cp)) = o;
+      }
+      return;
+    }
     {
       const int r = threadIdx.x & 31, cp = cp0 + r;
 #pragma unroll

@@ -168,7 +168,9 @@ def test_every_layer_backward_from_the_executors_own_buffers(name, batch, dtype,
       # dgamma / dbeta are sums of terms of both signs gated by the ReLU mask: an element whose
       # pre-activation is within rounding of zero flips its mask bit between two evaluations of
       # the same formula and moves the sum by one term, ~1/sqrt(P) of the total
-      bound = max(tol, 1e-2) if op.kind == "bn" else tol
+      # (a flipped bit also moves the weight gradients of the layers behind it: the same allowance
+      # as for the activation gradients below)
+      bound = max(tol, 1e-2) if op.kind == "bn" else max(tol, 8e-3)
       assert r <= bound, (op.name, k, r)
       worst = max(worst, (op.name + "/" + k, r), key=lambda p: p[1])
       checked_vars += 1
