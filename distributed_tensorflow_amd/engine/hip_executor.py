@@ -100,6 +100,7 @@ class HipExecutor:
   native = True
   # rows of atomically accumulated BatchNorm sums per layer (ResNet-50 step: 8 rows 20.30 ms, 16: 20.13, 32: 20.12, 64: 20.18)
   STATS_REPLICAS = int(os.environ.get("DTF_BN_STATS_REPLICAS", "32"))
+  _PIPE_F16_CFGS = (17, 18, 20, 21, 23, 24, 30, 31)   # pipeline tiles instantiated for IEEE half
   # A data gradient also accumulates the backward statistics of the BatchNorm it feeds when the
   # gradient tensor is at most this many bytes.  The epilogue re-reads the BatchNorm input at
   # the size of its output: for small tensors that replaces a reduction sweep which is pure
@@ -394,10 +395,17 @@ class HipExecutor:
     # the recomputed value (and its backward statistics are not accumulated by a data gradient,
     # which would need the mask bits of the apply sweep).  DTF_BN_IN_TILE=0: never, 2: the
     # whole-rows tiles wherever they serve the layer, whatever the table says.
+    # The same for a pointwise consumer (the BatchNorm in front of the last layer of every
+    # bottleneck block): the pipeline kernel and the general weight-gradient kernel transform
+    # their operand fragments in registers, the layers are bound by their memory traffic and the
+    # vector unit is idle (ResNet-50 bs256: 19.10 - 19.20 -> 19.03 ms per step on one machine).
     self._bn_in_tile: Dict[str, Op] = {}        # BatchNorm name -> consumer convolution
     self._in_tile_of: Dict[str, Op] = {}        # convolution name -> BatchNorm
     self._in_tile_cfg: Dict[str, Tuple[int, int]] = {}   # convolution name -> (forward, weight-gradient) tile
     in_tile = os.environ.get("DTF_BN_IN_TILE", "1")
+    in_frag = os.environ.get("DTF_BN_IN_FRAG", "1")
+    in_frag_bytes = int(os.environ.get("DTF_BN_IN_FRAG_BYTES", "0"))
+    in_frag_force = int(os.environ.get("DTF_BN_IN_FRAG_FORCE_BYTES", str(64 << 20)))
     if self.fused_bn_stats and self.dt in (0, 1) and in_tile != "0":
       users = {}
       for op in spec.ops:
@@ -419,8 +427,26 @@ class HipExecutor:
         if in_tile == "2":               # tests: the whole-rows tiles wherever they serve the layer
           fd = next((dict(fd, cfg=c) for c in (52, 49) if native.ext().conv_rows_serves(dict(fd, cfg=c))), fd)
           wd = dict(wd, cfg=192)
+        if in_frag != "0" and g.KH == 1 and g.KW == 1 and not 16 <= fd.get("cfg", 0) < 32:
+          # a layer the table gives to the two-stage kernel: the pipeline tile that is closest
+          # (2 in tests: every pointwise consumer, whatever its size)
+          if in_frag == "2":
+            fd = dict(fd, cfg=20)
+          elif g.N * g.H * g.W * g.Cin * self.esize >= in_frag_force:
+            fd = dict(fd, cfg=int(os.environ.get("DTF_BN_IN_FRAG_CFG", "17")))
         if (48 <= fd.get("cfg", 0) < 54 and native.ext().conv_rows_serves(fd)
             and wd.get("cfg") == 192 and native.ext().wgrad_rows_serves(wd)):
+          self._bn_in_tile[b.name] = u[0]
+          self._in_tile_of[u[0].name] = b
+          self._in_tile_cfg[u[0].name] = (fd["cfg"], wd["cfg"])
+        elif (in_frag != "0" and g.KH == 1 and g.KW == 1 and g.stride == 1 and g.mode == "normal"
+              and g.Cs == g.Cin and g.Cin <= 512 and g.Cin % 32 == 0
+              and g.N * g.H * g.W * g.Cin * self.esize >= in_frag_bytes
+              and fd.get("cfg", 0) in (self._PIPE_F16_CFGS if self.dt == 1 else range(16, 32))):
+          # pointwise consumer: the pipeline kernel and the general weight-gradient kernel apply
+          # scale / shift / ReLU to their fragments between the LDS read and the matrix
+          # instructions (DTF_BN_IN_FRAG=0: never, 2: with a pipeline tile whatever the table says;
+          # DTF_BN_IN_FRAG_BYTES: smallest input tensor)
           self._bn_in_tile[b.name] = u[0]
           self._in_tile_of[u[0].name] = b
           self._in_tile_cfg[u[0].name] = (fd["cfg"], wd["cfg"])
@@ -663,7 +689,9 @@ class HipExecutor:
   def _add(self, plan, kind: str, desc: Dict, name: str, lane: int = 0):
     """plan.add with the measured tile configuration of this shape, when one is known."""
     # a launch that normalises its input inside the tile keeps the whole-rows tile it was planned with
-    pinned = desc.get("cfg") if desc.get("in_scale") is not None or desc.get("x_scale") is not None else None
+    # (a pointwise weight gradient that normalises X on its fragments runs any general tile)
+    pinned = desc.get("cfg") if desc.get("in_scale") is not None or \
+        (desc.get("x_scale") is not None and desc.get("cfg") == 192) else None
     if kind in ("conv", "wgrad"):
       desc = autotune.apply(kind, desc)
     if kind in ("conv", "wgrad") and desc.get("batch") is None:
@@ -1250,8 +1278,9 @@ class HipExecutor:
           b = self._in_tile_of[op.name]
           sp = self.bn_saved.data_ptr() + 4 * self._bn_off[b.name]
           cb = b.attrs["channels"]
-          wdesc.update(x=acts[b.inputs[0]].data_ptr(), x_scale=sp + 8 * cb, x_shift=sp + 12 * cb,
-                       cfg=self._in_tile_cfg[op.name][1])
+          wdesc.update(x=acts[b.inputs[0]].data_ptr(), x_scale=sp + 8 * cb, x_shift=sp + 12 * cb)
+          if self._in_tile_cfg[op.name][1] == 192:
+            wdesc.update(cfg=192)
         self._add_wgrad(plan, wdesc, op.name + "/wgrad")
         if (op is not first_conv and g.has_empty_parities() and defer_ok
             and uses_left.get(xname, 0) > 1 and xname not in written and xname not in pending

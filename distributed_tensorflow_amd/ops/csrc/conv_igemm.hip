@@ -545,12 +545,12 @@ void launch_conv_igemm(const ConvParams& p, int cfg, hipStream_t stream) {
     if (launch_conv_rows(p, cfg, stream)) return;
     cfg = rows_fallback_cfg(cfg);
   }
-  if (p.in_scale)
-    throw std::invalid_argument("conv: normalising the input inside the tile needs a whole-rows 3x3 configuration (48..53) that serves the layer");
   if (cfg >= 16 && cfg < 32) {
     if (p.dt != DT_F32 && launch_conv_pipe(p, cfg, stream)) return;
     cfg = pipe_fallback_cfg(cfg);
   }
+  if (p.in_scale)
+    throw std::invalid_argument("conv: normalising the input inside the tile needs a whole-rows 3x3 configuration (48..53) or, for a pointwise layer of at most 512 channels, a pipeline configuration (16..31) that serves the layer");
   switch (cfg) {
     case 0: launch_cfg<128, 128, 2, 2>(p, stream); break;
     case 1: launch_cfg<256, 64, 4, 1>(p, stream); break;

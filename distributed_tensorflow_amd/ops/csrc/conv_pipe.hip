@@ -64,8 +64,9 @@ __device__ __forceinline__ int swz_w(int row) {
 }
 
 // waves per SIMD the register allocation has to allow: as many blocks as the LDS ring admits
-constexpr int pipe_occ(int bm, int bn, int nw, int bk, int stages) {
-  const int lds = stages * (bm + bn) * bk * 2;
+constexpr int INBN_KMAX = 512;                      // channels of an input normalised in the fragments
+constexpr int pipe_occ(int bm, int bn, int nw, int bk, int stages, bool inbn = false) {
+  const int lds = stages * (bm + bn) * bk * 2 + (inbn ? INBN_KMAX * 8 : 0);
   int bpc = (160 * 1024) / lds;
   if (bpc < 1) bpc = 1;
   int w = bpc * nw / 4;
@@ -77,13 +78,19 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// INBN (pointwise layers): the BatchNorm + ReLU of the layer in front runs on the pixel fragments
+// between their LDS read and the matrix instructions, x := max(x * in_scale[k] + in_shift[k], 0)
+// with the constants in an LDS table behind the ring - the normalised tensor is never written.  A
+// fragment is transformed by each of the WAVES_N waves that multiply it; the layers this serves
+// are bound by their memory traffic and leave the vector unit idle.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int STAGES, int MODE, int EPI,
-          int DT = DT_BF16>
+          int DT = DT_BF16, bool INBN = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N,
-                             pipe_occ(BM, BN, WAVES_M * WAVES_N, BK, STAGES))
+                             pipe_occ(BM, BN, WAVES_M * WAVES_N, BK, STAGES, INBN))
 void conv_pipe_kernel(const ConvParams p) {
   static_assert(DT == DT_BF16 || DT == DT_F16, "16-bit element types");
   constexpr bool POINTWISE = MODE == POINTWISE_MODE;
+  static_assert(!INBN || POINTWISE, "fragment BatchNorm: pointwise layers");
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int CPR = BK / 8;                       // 16-byte chunks per tile row
   constexpr int ROWB = BK * 2;                      // bytes per tile row
@@ -100,7 +107,7 @@ void conv_pipe_kernel(const ConvParams p) {
   static_assert((STAGES - 1) * LPS < 64, "vmcnt range");
 
   // all LDS in one array (a second __shared__ object makes the compiler drain the DMA early)
-  __shared__ __attribute__((aligned(16))) uint8_t smem[STAGES * SBYTES];
+  __shared__ __attribute__((aligned(16))) uint8_t smem[STAGES * SBYTES + (INBN ? INBN_KMAX * 8 : 0)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -252,6 +259,15 @@ void conv_pipe_kernel(const ConvParams p) {
     conv_epi::addend_fetch<NR, POINTWISE, EPI, DT>(p, ahead, m0 + wm * WM + (lane & 15),
                                                    n0 + wn * WN + (lane >> 4) * 4 * NR);
   const int KT = (p.Ktotal + BK - 1) / BK;
+  float* const bntab = reinterpret_cast<float*>(smem + STAGES * SBYTES);   // [scale | shift]
+  if constexpr (INBN) {
+    // channels past Ktotal multiply weight chunks of zeros: any finite constant will do
+    for (int k = tid; k < INBN_KMAX; k += 64 * NW) {
+      bntab[k] = k < p.Ktotal ? p.in_scale[k] : 0.f;
+      bntab[INBN_KMAX + k] = k < p.Ktotal ? p.in_shift[k] : 0.f;
+    }
+    // visible to every wave after the barrier of the first K-step (which waits for lgkmcnt(0))
+  }
   setup_tap();
   // prologue: the first STAGES - 1 steps
   int issue_byte = 0;                               // ring position of the next stage to fill
@@ -290,6 +306,27 @@ void conv_pipe_kernel(const ConvParams p) {
 #pragma unroll
       for (int mr = 0; mr < MR; ++mr)
         xf[mr] = *reinterpret_cast<const u32x4*>(st + (xoff[mr] ^ (ks << 6)));
+      if constexpr (INBN) {
+        // the lane's eight reduction channels of this step: kt * BK + ks * 32 + fq * 8 ...
+        const float* tsc = bntab + kt * BK + ks * 32 + fq * 8;
+        const f32x4 sa = *reinterpret_cast<const f32x4*>(tsc), sb = *reinterpret_cast<const f32x4*>(tsc + 4);
+        const f32x4 ha = *reinterpret_cast<const f32x4*>(tsc + INBN_KMAX),
+                    hb = *reinterpret_cast<const f32x4*>(tsc + INBN_KMAX + 4);
+        const float sc[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
+        const float sh[8] = {ha[0], ha[1], ha[2], ha[3], hb[0], hb[1], hb[2], hb[3]};
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+          const uint32_t w[4] = {xf[mr].x, xf[mr].y, xf[mr].z, xf[mr].w};
+          uint32_t o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float lo = fmaxf(lo16<DT>(w[j]) * sc[2 * j] + sh[2 * j], 0.f);
+            const float hi = fmaxf(hi16<DT>(w[j]) * sc[2 * j + 1] + sh[2 * j + 1], 0.f);
+            o[j] = pack2<DT>(lo, hi);
+          }
+          xf[mr] = u32x4{o[0], o[1], o[2], o[3]};
+        }
+      }
 #pragma unroll
       for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
@@ -312,6 +349,18 @@ bool launch_pipe_epi(const ConvParams& p, hipStream_t stream) {
                          p.dw0 == 0 && p.OSH == 1 && p.OSW == 1 && p.OOH == 0 && p.OOW == 0 &&
                          p.OH == p.H && p.OW == p.W && p.OHfull == p.OH && p.OWfull == p.OW &&
                          p.Ctap <= p.Cpix;
+  if (p.in_scale) {
+    // BatchNorm + ReLU of the input on the fragments: pointwise layers with a plain or
+    // forward-statistics epilogue, at most INBN_KMAX channels, ring + table within the LDS
+    if constexpr ((EPI == EPI_PLAIN) && STAGES * (BM + BN) * BK * 2 + INBN_KMAX * 8 <= 160 * 1024) {
+      if (!pointwise || p.Ktotal > INBN_KMAX) return false;
+      hipLaunchKernelGGL((conv_pipe_kernel<BM, BN, WAVES_M, WAVES_N, BK, STAGES, POINTWISE_MODE, EPI, DT, true>),
+                         dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, stream, p);
+      return true;
+    } else {
+      return false;
+    }
+  }
   if (pointwise)
     hipLaunchKernelGGL((conv_pipe_kernel<BM, BN, WAVES_M, WAVES_N, BK, STAGES, POINTWISE_MODE, EPI, DT>),
                        dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, stream, p);

@@ -98,11 +98,19 @@ constexpr int wgrad_occ(int bkk, int bco, int threads, int g, int stages, int es
 // DT: element type of X and dY.  bf16 / fp16 use the transposing reads and
 // v_mfma_f32_16x16x32_{bf16,f16}; fp32 reads single elements (a lane owns channel lane % 16 of
 // pixel 4 * step + lane / 16) and runs v_mfma_f32_16x16x4_f32, eight per 32-pixel step.
-template <int DT, int BKK, int BCO, int WAVES_K, int WAVES_C, int G, bool POINTWISE, int STAGES>
+//
+// XBN (pointwise layers, 16-bit types): X is the raw input of a BatchNorm + ReLU that the forward
+// launch applied on its own fragments; the same x := max(x * x_scale[k] + x_shift[k], 0) runs here
+// on the transposed fragments (a lane's eight pixels belong to one channel: two constants per
+// fragment row live in registers for the whole reduction).  Pixels past the end transform a zero
+// into max(shift, 0) and meet a dY of zero.
+template <int DT, int BKK, int BCO, int WAVES_K, int WAVES_C, int G, bool POINTWISE, int STAGES,
+          bool XBN = false>
 __global__ __launch_bounds__(64 * WAVES_K * WAVES_C * G,
                              wgrad_occ(BKK, BCO, 64 * WAVES_K * WAVES_C * G, G, STAGES,
                                        DT == DT_F32 ? 4 : 2))
 void conv_wgrad_kernel(const WgradParams p) {
+  static_assert(!XBN || (POINTWISE && DT != DT_F32), "fragment BatchNorm: pointwise, 16-bit");
   typedef typename Elem<DT>::T T;
   constexpr int ES = (int)sizeof(T);
   constexpr int EPC = 16 / ES;                                  // elements per 16-byte chunk
@@ -230,6 +238,15 @@ void conv_wgrad_kernel(const WgradParams p) {
   // group g takes reduction steps g, g + G, ...; the trip count is the same for every group
   // (a step past the end loads zeros) because all of them meet at the block barrier
   const int nsteps = ((pend - pbeg + BP - 1) / BP + G - 1) / G;
+  float xsc[KR], xsh[KR];
+  if constexpr (XBN) {
+#pragma unroll
+    for (int a = 0; a < KR; ++a) {
+      const int k = k0 + wk * WKK + a * 16 + (lane & 15);
+      xsc[a] = k < p.Ktotal ? p.x_scale[k] : 0.f;
+      xsh[a] = k < p.Ktotal ? p.x_shift[k] : 0.f;
+    }
+  }
   auto multiply = [&](int sbyte) {
     const uint8_t* xs = smem + sbyte;
     const uint8_t* ys = xs + XBYTES;
@@ -259,6 +276,19 @@ void conv_wgrad_kernel(const WgradParams p) {
       bf16x8 xf[KR], yf[CR];
 #pragma unroll
       for (int a = 0; a < KR; ++a) xf[a] = read_tr_frag<BKK>(xs, wk * WKK + a * 16, lane);
+      if constexpr (XBN) {
+#pragma unroll
+        for (int a = 0; a < KR; ++a) {
+          const u32x4 v = __builtin_bit_cast(u32x4, xf[a]);
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+          uint32_t o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            o[j] = pack2<DT>(fmaxf(lo16<DT>(w[j]) * xsc[a] + xsh[a], 0.f),
+                             fmaxf(hi16<DT>(w[j]) * xsc[a] + xsh[a], 0.f));
+          xf[a] = __builtin_bit_cast(bf16x8, u32x4{o[0], o[1], o[2], o[3]});
+        }
+      }
 #pragma unroll
       for (int b = 0; b < CR; ++b) yf[b] = read_tr_frag<BCO>(ys, wc * WCO + b * 16, lane);
 #pragma unroll
@@ -380,6 +410,17 @@ void launch_stg(const WgradParams& p, hipStream_t stream) {
   const bool pointwise = p.TI == 1 && p.TJ == 1 && p.ISH == 1 && p.ISW == 1 && p.dh0 == 0 &&
                          p.dw0 == 0 && p.OH == p.H && p.OW == p.W && p.Ctap <= p.Cpix;
   dim3 grid(tilesK * tilesC, p.splits, p.batch ? p.nbatch : 1);
+  if (p.x_scale) {
+    if constexpr (DT != DT_F32) {
+      if (!pointwise || p.batch)
+        throw std::invalid_argument("conv_wgrad: normalising X on the fragments needs a single pointwise layer");
+      hipLaunchKernelGGL((conv_wgrad_kernel<DT, BKK, BCO, WAVES_K, WAVES_C, G, true, STAGES, true>), grid,
+                         dim3(64 * WAVES_K * WAVES_C * G), 0, stream, p);
+      return;
+    } else {
+      throw std::invalid_argument("conv_wgrad: normalising X on the fragments is for 16-bit element types");
+    }
+  }
   if (pointwise)
     hipLaunchKernelGGL((conv_wgrad_kernel<DT, BKK, BCO, WAVES_K, WAVES_C, G, true, STAGES>), grid,
                        dim3(64 * WAVES_K * WAVES_C * G), 0, stream, p);
@@ -468,8 +509,6 @@ void launch_conv_wgrad(const WgradParams& p, int cfg, hipStream_t stream) {
     if (launch_conv_wgrad_rows(p, cfg, stream)) return;
     cfg = 0;                   // a descriptor the whole-rows kernel cannot serve: the 128x128 tile
   }
-  if (p.x_scale)
-    throw std::invalid_argument("conv_wgrad: normalising X inside the tile needs the whole-rows kernel (cfg 192) to serve the layer");
   if (cfg < 0 || cfg >= 192 || (cfg % 64) >= 48)
     throw std::invalid_argument("conv_wgrad: unknown tile config");
   const int stages = 2 + cfg / 64;

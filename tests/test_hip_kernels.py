@@ -1433,6 +1433,71 @@ def test_whole_rows_weight_gradient_normalises_x_inside_the_tile(N, HW, C):
     native.run_op("wgrad", dict(d, cfg=1))
 
 
+@pytest.mark.parametrize("case,cfg", [((3, 56, 56, 64, 256), 17), ((3, 56, 56, 64, 256), 31), ((2, 28, 28, 128, 512), 30),
+                                      ((5, 14, 14, 256, 1024), 20), ((7, 7, 7, 512, 2048), 18), ((2, 28, 28, 96, 40), 16),
+                                      ((33, 56, 56, 64, 256), 23)])
+def test_pipeline_kernel_normalises_the_input_of_a_pointwise_layer_on_its_fragments(case, cfg):
+  """conv_pipe.hip with `in_scale` / `in_shift` on a 1x1 layer: BatchNorm + ReLU of the layer in front applied
+  to the pixel fragments between the LDS read and the matrix instructions.  Bit for bit the same launch on a
+  tensor normalised beforehand, statistics included; a ragged K (96 channels) and a ragged pixel count too."""
+  native = _native()
+  N, H, W, Cin, Cout = case
+  tdt = torch.bfloat16
+  dev = torch.device("cuda")
+  gen = torch.Generator(device="cpu").manual_seed(cfg + Cin)
+  g = ConvGeom(N, H, W, Cin, 1, 1, Cout, 1, (0, 0, 0, 0))
+  y = torch.randn(N, H, W, Cin, generator=gen).to(tdt).to(dev)
+  scale = (torch.rand(Cin, generator=gen) + 0.5).to(dev)
+  shift = (torch.randn(Cin, generator=gen) * 0.5 + 0.3).to(dev)
+  a = _affine_relu(y, scale, shift)
+  w = (torch.randn(1, 1, Cin, Cout, generator=gen) * 0.05).to(dev)
+  wf = _pack(native, g, w, "fwd")
+  out_ref = torch.zeros(g.output_shape, dtype=tdt, device=dev)
+  out = torch.zeros_like(out_ref)
+  stats_ref = torch.zeros(32, 2, Cout, device=dev)
+  stats = torch.zeros_like(stats_ref)
+  native.run_op("conv", g.fwd(a.data_ptr(), wf.data_ptr(), out_ref.data_ptr(), cfg=cfg,
+                              stats=stats_ref.data_ptr(), stats_replicas=32))
+  d = dict(g.fwd(y.data_ptr(), wf.data_ptr(), out.data_ptr(), cfg=cfg, stats=stats.data_ptr(), stats_replicas=32),
+           in_scale=scale.data_ptr(), in_shift=shift.data_ptr())
+  native.run_op("conv", d)
+  torch.cuda.synchronize()
+  assert torch.equal(out, out_ref)
+  assert torch.allclose(stats.sum(0), stats_ref.sum(0), rtol=1e-4, atol=1e-2)
+  ref = _ref_conv(a.float(), w.to(tdt).float(), 1, (0, 0, 0, 0))
+  assert (out[..., :Cout].float() - ref).abs().max().item() <= 0.02 * ref.abs().max().item() + 1e-2
+  with pytest.raises(ValueError):
+    native.run_op("conv", dict(d, cfg=0))      # the two-stage kernel has no such operand path
+
+
+@pytest.mark.parametrize("N,HW,Cin,Cout,cfg", [(3, 56, 64, 256, 1), (3, 56, 64, 256, 64 + 17), (2, 28, 128, 512, 0),
+                                               (5, 14, 256, 1024, 128 + 0), (3, 7, 512, 2048, 16 + 8),
+                                               (2, 28, 96, 40, 2)])
+def test_weight_gradient_normalises_x_of_a_pointwise_layer_on_its_fragments(N, HW, Cin, Cout, cfg):
+  """conv_wgrad.hip with `x_scale` / `x_shift` on a 1x1 layer against the same launch on a normalised X
+  (one split: the same summation order)."""
+  native = _native()
+  dev = torch.device("cuda")
+  gen = torch.Generator(device="cpu").manual_seed(N + cfg)
+  g = ConvGeom(N, HW, HW, Cin, 1, 1, Cout, 1, (0, 0, 0, 0))
+  y = _bf(torch.randn(N, HW, HW, Cin, generator=gen)).to(dev)
+  scale = (torch.rand(Cin, generator=gen) + 0.5).to(dev)
+  shift = (torch.randn(Cin, generator=gen) * 0.5 + 0.3).to(dev)
+  a = _affine_relu(y, scale, shift)
+  dy = _bf(torch.randn(g.output_shape, generator=gen)).to(dev)
+  dw_ref = torch.zeros(1, 1, Cin, Cout, device=dev)
+  dw = torch.zeros_like(dw_ref)
+  native.run_op("wgrad", g.wgrad(a.data_ptr(), dy.data_ptr(), dw_ref.data_ptr(), cfg=cfg, splits=1))
+  d = dict(g.wgrad(y.data_ptr(), dy.data_ptr(), dw.data_ptr(), cfg=cfg, splits=1),
+           x_scale=scale.data_ptr(), x_shift=shift.data_ptr())
+  native.run_op("wgrad", d)
+  torch.cuda.synchronize()
+  assert torch.equal(dw, dw_ref)
+  wr = torch.zeros(1, 1, Cin, Cout, device=dev).requires_grad_(True)
+  _ref_conv(a.float(), wr, 1, (0, 0, 0, 0)).backward(dy[..., :Cout].float())
+  assert (dw - wr.grad).abs().max().item() <= 2e-3 * wr.grad.abs().max().item() + 1e-3
+
+
 @pytest.mark.parametrize("P,C", [(70001, 64), (40003, 256)])
 def test_batchnorm_backward_takes_its_relu_mask_from_the_recomputed_value(P, C):
   """bn_bwd with `relu_scale` / `relu_shift` (mask = y * scale + shift > 0, for a layer whose forward

@@ -131,11 +131,19 @@ class _Teacher:
 
 @pytest.mark.parametrize("name,batch,dtype,tol", [
     ("resnet20", 16, "fp32", 5e-3), ("resnet50", 8, "fp32", 5e-3),
-    ("resnet20", 16, "bf16", 1e-2), ("resnet50", 8, "bf16", 1e-2),
+    ("resnet20", 16, "bf16", 1e-2), ("resnet50", 8, "bf16", 1e-2), ("resnet50", 8, "bf16+frag", 1e-2),
+    ("resnet50", 8, "fp16+frag", 1e-2),
 ])
 def test_every_layer_backward_from_the_executors_own_buffers(name, batch, dtype, tol, monkeypatch):
   from distributed_tensorflow_amd.engine.hip_executor import HipExecutor
   from distributed_tensorflow_amd.engine.params import ParamStore
+  frag = dtype.endswith("+frag")
+  if frag:
+    # the BatchNorms in front of pointwise layers too: applied to the fragments of the pipeline kernel
+    # and of the weight gradient
+    dtype = dtype[:-5]
+    monkeypatch.setenv("DTF_BN_IN_FRAG", "2")
+    monkeypatch.setenv("DTF_BN_PROLOGUE_BYTES", "0")     # (at this batch size the halo kernel's prologue would take them)
   if name == "resnet50" and dtype == "bf16":
     # also the BatchNorms that are applied inside their consumer's tile (at this batch size their
     # tensors are small and would otherwise keep the apply sweep)
@@ -185,6 +193,10 @@ def test_every_layer_backward_from_the_executors_own_buffers(name, batch, dtype,
     assert r <= max(tol, 8e-3), (tname, r)
     checked_acts += 1
   if name == "resnet50" and dtype == "bf16":
-    assert len(hx._bn_in_tile) == 6          # the BatchNorm in front of the 56x56x64 and 28x28x128 3x3 layers
+    # the BatchNorm in front of the 56x56x64 and 28x28x128 3x3 layers (+ the sixteen in front of the
+    # last pointwise layer of a block)
+    assert len(hx._bn_in_tile) == (22 if frag else 6)
+  elif frag:
+    assert len(hx._bn_in_tile) >= 16
   assert checked_vars == len(store.trainable)
   assert checked_acts >= len([o for o in spec.ops if o.kind in ("conv", "dense")]) - 1

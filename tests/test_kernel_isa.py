@@ -64,9 +64,15 @@ def _loop_barriers(ins):
 
 
 def _has_vm_wait(ins, b):
-  for s in ins[max(0, b - WINDOW):b]:
+  """A vmcnt wait within WINDOW instructions before the barrier, or further back (a kernel that
+  transforms its fragments in registers has some forty vector instructions between the wait and the
+  barrier) with nothing but arithmetic in between: no memory instruction, branch or barrier."""
+  for k, s in enumerate(reversed(ins[max(0, b - 8 * WINDOW):b])):
     if s.startswith("s_waitcnt") and "vmcnt(" in s:
       return True
+    if k >= WINDOW and s.startswith(("global_", "buffer_", "flat_", "scratch_", "ds_", "s_cbranch", "s_branch",
+                                     "s_barrier", "s_load", "s_endpgm")):
+      return False
   return False
 
 
