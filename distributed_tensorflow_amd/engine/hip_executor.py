@@ -398,13 +398,15 @@ class HipExecutor:
     # The same for a pointwise consumer (the BatchNorm in front of the last layer of every
     # bottleneck block): the pipeline kernel and the general weight-gradient kernel transform
     # their operand fragments in registers, the layers are bound by their memory traffic and the
-    # vector unit is idle (ResNet-50 bs256: 19.10 - 19.20 -> 19.03 ms per step on one machine).
+    # vector unit is idle (ResNet-50 bs256: 19.13 -> 19.01 ms per step in an alternating A/B on one machine).
     self._bn_in_tile: Dict[str, Op] = {}        # BatchNorm name -> consumer convolution
     self._in_tile_of: Dict[str, Op] = {}        # convolution name -> BatchNorm
     self._in_tile_cfg: Dict[str, Tuple[int, int]] = {}   # convolution name -> (forward, weight-gradient) tile
     in_tile = os.environ.get("DTF_BN_IN_TILE", "1")
     in_frag = os.environ.get("DTF_BN_IN_FRAG", "1")
-    in_frag_bytes = int(os.environ.get("DTF_BN_IN_FRAG_BYTES", "0"))
+    # (ResNet-50 bs256, per step: off 19.13 ms, from 60 MB 19.07, from 40 MB 19.02, from 20 MB 19.01,
+    # every layer 19.07 - a small layer loses more with its own backward reduction sweep than it saves)
+    in_frag_bytes = int(os.environ.get("DTF_BN_IN_FRAG_BYTES", str(20 << 20))) if in_frag != "2" else 0
     in_frag_force = int(os.environ.get("DTF_BN_IN_FRAG_FORCE_BYTES", str(64 << 20)))
     if self.fused_bn_stats and self.dt in (0, 1) and in_tile != "0":
       users = {}
