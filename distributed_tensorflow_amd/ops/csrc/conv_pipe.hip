@@ -325,7 +325,13 @@ void conv_pipe_kernel(const ConvParams p) {
             o[j] = pack2<DT>(lo, hi);
           }
           xf[mr] = u32x4{o[0], o[1], o[2], o[3]};
+          // (a fragment in front of its own products: the vector instructions of fragment mr + 1
+          // run while the matrix unit works on fragment mr)
+#pragma unroll
+          for (int nr = 0; nr < NR; ++nr)
+            acc[nr][mr] = mfma_step<DT>(wf[nr], xf[mr], acc[nr][mr]);
         }
+        continue;
       }
 #pragma unroll
       for (int nr = 0; nr < NR; ++nr)

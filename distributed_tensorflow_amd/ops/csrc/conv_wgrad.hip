@@ -276,9 +276,13 @@ void conv_wgrad_kernel(const WgradParams p) {
       bf16x8 xf[KR], yf[CR];
 #pragma unroll
       for (int a = 0; a < KR; ++a) xf[a] = read_tr_frag<BKK>(xs, wk * WKK + a * 16, lane);
-      if constexpr (XBN) {
 #pragma unroll
-        for (int a = 0; a < KR; ++a) {
+      for (int b = 0; b < CR; ++b) yf[b] = read_tr_frag<BCO>(ys, wc * WCO + b * 16, lane);
+#pragma unroll
+      for (int a = 0; a < KR; ++a) {
+        if constexpr (XBN) {
+          // one fragment row at a time, in front of its own products: the vector instructions of
+          // row a + 1 run while the matrix unit works on row a
           const u32x4 v = __builtin_bit_cast(u32x4, xf[a]);
           const uint32_t w[4] = {v.x, v.y, v.z, v.w};
           uint32_t o[4];
@@ -288,11 +292,6 @@ void conv_wgrad_kernel(const WgradParams p) {
                              fmaxf(hi16<DT>(w[j]) * xsc[a] + xsh[a], 0.f));
           xf[a] = __builtin_bit_cast(bf16x8, u32x4{o[0], o[1], o[2], o[3]});
         }
-      }
-#pragma unroll
-      for (int b = 0; b < CR; ++b) yf[b] = read_tr_frag<BCO>(ys, wc * WCO + b * 16, lane);
-#pragma unroll
-      for (int a = 0; a < KR; ++a)
 #pragma unroll
         for (int b = 0; b < CR; ++b) {
           if constexpr (DT == DT_F16)
@@ -301,6 +300,7 @@ void conv_wgrad_kernel(const WgradParams p) {
           else
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], yf[b], acc[a][b], 0, 0, 0);
         }
+      }
     }
   };
   if constexpr (STAGES == 2) {
