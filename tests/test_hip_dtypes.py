@@ -284,7 +284,10 @@ def _rel(a, b):
   return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
 
 
-@pytest.mark.parametrize("name,batch,bound", [("resnet20", 16, 1e-2), ("resnet50", 8, 8e-2)])
+# (resnet20: the statistics come out of the convolution epilogues through float atomics, so their last
+# bits vary from run to run, and with them a ReLU mask bit at a pre-activation within rounding of zero;
+# one flipped bit moves a dbeta of 16 x 32 x 32 terms by ~1 / sqrt(P) = 0.8 % - observed 0.4 - 1.1 %)
+@pytest.mark.parametrize("name,batch,bound", [("resnet20", 16, 2e-2), ("resnet50", 8, 8e-2)])
 def test_fp32_step_matches_pytorch_fp32_per_variable(name, batch, bound):
   """The whole planned step in fp32 against PyTorch autograd in fp32: loss and forward statistics
   to 1e-4, the gradient of *every* variable to the bound two correct fp32 implementations reach on
